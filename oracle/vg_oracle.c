@@ -1,0 +1,1491 @@
+/*
+ * vg_oracle.c — CPU ORACLE (test infrastructure only; see vg_oracle.h).
+ *
+ * Scalar f64 restatement of the reference's per-glyph SDF path.  Every function cites
+ * the reference file:line it follows (paths relative to /root/reference/).  Compile
+ * with -ffp-contract=off (Rust never fuses a*b+c).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "vg_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* src/render/mod.rs:52-68 */
+#define GLYPH_SIZE 24
+#define BUFFER 3
+#define SDF_RADIUS 8.0
+#define CUTOFF (0.25 * 256.0)
+#define MAX_COMPONENTS 32 /* ttf-parser glyf.rs */
+
+/* ------------------------------------------------------------------------------------
+ * big-endian stream helpers
+ * ---------------------------------------------------------------------------------- */
+static inline int rd_ok(size_t len, size_t off, size_t n) { return off <= len && n <= len - off; }
+static inline uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
+static inline uint32_t be32(const uint8_t *p)
+{
+	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+typedef struct {
+	const uint8_t *p;
+	size_t len;
+} span;
+
+struct vgo_font {
+	uint8_t *data;
+	size_t len;
+	span head, maxp, hhea, hmtx, loca, glyf, cmap;
+	int units_per_em, num_glyphs, num_hmetrics, loca_long;
+	size_t loca_count;
+};
+
+static span find_table(const uint8_t *d, size_t len, const char *tag)
+{
+	span s = {NULL, 0};
+	if (len < 12)
+		return s;
+	int n = be16(d + 4);
+	for (int i = 0; i < n; i++) {
+		size_t r = 12 + (size_t)i * 16;
+		if (!rd_ok(len, r, 16))
+			break;
+		if (memcmp(d + r, tag, 4) == 0) {
+			size_t off = be32(d + r + 8), l = be32(d + r + 12);
+			if (rd_ok(len, off, l)) {
+				s.p = d + off;
+				s.len = l;
+			}
+			return s;
+		}
+	}
+	return s;
+}
+
+/* ttf_parser::Face::parse — only the tables the render path touches */
+vgo_font *vgo_font_open(const uint8_t *data, size_t len)
+{
+	vgo_font *f = (vgo_font *)calloc(1, sizeof *f);
+	f->data = (uint8_t *)malloc(len ? len : 1);
+	memcpy(f->data, data, len);
+	f->len = len;
+	f->head = find_table(f->data, len, "head");
+	f->maxp = find_table(f->data, len, "maxp");
+	f->hhea = find_table(f->data, len, "hhea");
+	f->hmtx = find_table(f->data, len, "hmtx");
+	f->loca = find_table(f->data, len, "loca");
+	f->glyf = find_table(f->data, len, "glyf");
+	f->cmap = find_table(f->data, len, "cmap");
+	if (!f->head.p || f->head.len < 54 || !f->maxp.p || f->maxp.len < 6 || !f->hhea.p ||
+	    f->hhea.len < 36) {
+		vgo_font_close(f);
+		return NULL;
+	}
+	f->units_per_em = be16(f->head.p + 18);
+	if (f->units_per_em < 16 || f->units_per_em > 16384) { /* ttf-parser head.rs */
+		vgo_font_close(f);
+		return NULL;
+	}
+	f->loca_long = (int16_t)be16(f->head.p + 50) != 0;
+	f->num_glyphs = be16(f->maxp.p + 4);
+	f->num_hmetrics = be16(f->hhea.p + 34);
+	if (f->loca.p) {
+		size_t total = (size_t)f->num_glyphs + 1; /* ttf-parser loca.rs */
+		if (f->num_glyphs == 0xFFFF)
+			total = 0xFFFF;
+		size_t actual = f->loca.len / (f->loca_long ? 4 : 2);
+		f->loca_count = actual < total ? actual : total;
+	}
+	return f;
+}
+
+void vgo_font_close(vgo_font *f)
+{
+	if (!f)
+		return;
+	free(f->data);
+	free(f);
+}
+
+int vgo_font_units_per_em(const vgo_font *f) { return f->units_per_em; }
+int vgo_font_num_glyphs(const vgo_font *f) { return f->num_glyphs; }
+
+/* ttf-parser hmtx.rs Table::advance (call site renderer.rs:115) */
+int vgo_font_hor_advance(const vgo_font *f, int gid)
+{
+	if (!f->hmtx.p || f->num_hmetrics == 0 || f->num_glyphs == 0)
+		return -1;
+	if (gid < 0 || gid >= f->num_glyphs)
+		return -1;
+	size_t have = f->hmtx.len / 4;
+	size_t nm = (size_t)f->num_hmetrics;
+	if (have < nm)
+		return -1; /* read_array16 fails -> no hmtx table */
+	size_t idx = (size_t)gid < nm ? (size_t)gid : nm - 1; /* last long metric repeats */
+	return be16(f->hmtx.p + idx * 4);
+}
+
+/* ------------------------------------------------------------------------------------
+ * cmap (ttf-parser tables/cmap/ *.rs; call sites renderer.rs:106, metadata.rs:105-117)
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	int platform, encoding, format;
+	span d; /* from the subtable offset to the end of the cmap table */
+} cmap_sub;
+
+static int cmap_subtable(const vgo_font *f, int i, cmap_sub *out)
+{
+	span c = f->cmap;
+	if (!c.p || c.len < 4)
+		return 0;
+	int n = be16(c.p + 2);
+	if (i >= n)
+		return 0;
+	size_t r = 4 + (size_t)i * 8;
+	if (!rd_ok(c.len, r, 8))
+		return 0;
+	out->platform = be16(c.p + r);
+	out->encoding = be16(c.p + r + 2);
+	size_t off = be32(c.p + r + 4);
+	out->format = -1;
+	out->d.p = NULL;
+	out->d.len = 0;
+	if (off <= c.len && c.len - off >= 2) {
+		out->d.p = c.p + off;
+		out->d.len = c.len - off;
+		out->format = be16(out->d.p);
+	}
+	return 1;
+}
+
+/* cmap Subtable::is_unicode */
+static int sub_is_unicode(const cmap_sub *s)
+{
+	if (s->platform == 0)
+		return 1;
+	if (s->platform == 3 && s->encoding == 1)
+		return 1;
+	if (s->platform == 3)
+		return s->encoding == 10 && (s->format == 12 || s->format == 13);
+	return 0;
+}
+
+/* returns glyph id or -1 (None) */
+static int sub_glyph_index(const cmap_sub *s, uint32_t cp)
+{
+	const uint8_t *d = s->d.p;
+	size_t len = s->d.len;
+	switch (s->format) {
+	case 0: {
+		if (len < 6 + 256 || cp >= 256)
+			return -1;
+		int g = d[6 + cp];
+		return g != 0 ? g : -1;
+	}
+	case 4: { /* format4.rs: custom binary search over end codes */
+		if (cp > 0xFFFF || len < 16)
+			return -1;
+		uint16_t c16 = (uint16_t)cp;
+		unsigned segx2 = be16(d + 6);
+		if (segx2 < 2)
+			return -1;
+		size_t seg = segx2 / 2;
+		size_t end_off = 14, start_off = end_off + seg * 2 + 2, delta_off = start_off + seg * 2,
+		       ro_off = delta_off + seg * 2;
+		if (!rd_ok(len, ro_off, seg * 2))
+			return -1;
+		size_t lo = 0, hi = seg;
+		while (hi > lo) {
+			size_t idx = (lo + hi) / 2;
+			uint16_t endv = be16(d + end_off + idx * 2);
+			if (endv >= c16) {
+				uint16_t startv = be16(d + start_off + idx * 2);
+				if (startv > c16) {
+					hi = idx;
+				} else {
+					uint16_t ro = be16(d + ro_off + idx * 2);
+					int16_t delta = (int16_t)be16(d + delta_off + idx * 2);
+					if (ro == 0)
+						return (uint16_t)(c16 + (uint16_t)delta);
+					if (ro == 0xFFFF)
+						return -1;
+					uint32_t dl = ((uint32_t)c16 - (uint32_t)startv) * 2;
+					if (dl > 0xFFFF)
+						return -1;
+					uint16_t pos = (uint16_t)(ro_off + idx * 2);
+					pos = (uint16_t)(pos + (uint16_t)dl);
+					pos = (uint16_t)(pos + ro);
+					if (!rd_ok(len, pos, 2))
+						return -1;
+					uint16_t gv = be16(d + pos);
+					if (gv == 0)
+						return -1;
+					int16_t gid = (int16_t)((int16_t)gv + delta); /* wrapping i16 add */
+					return gid < 0 ? -1 : gid;
+				}
+			} else {
+				lo = idx + 1;
+			}
+		}
+		return -1;
+	}
+	case 6: {
+		if (cp > 0xFFFF || len < 10)
+			return -1;
+		unsigned first = be16(d + 6), count = be16(d + 8);
+		if (cp < first)
+			return -1;
+		uint32_t idx = cp - first;
+		if (idx >= count || !rd_ok(len, 10 + (size_t)idx * 2, 2))
+			return -1;
+		return be16(d + 10 + idx * 2);
+	}
+	case 10: {
+		if (len < 20)
+			return -1;
+		uint32_t first = be32(d + 12), count = be32(d + 16);
+		if (cp < first)
+			return -1;
+		uint32_t idx = cp - first;
+		if (idx >= count || !rd_ok(len, 20 + (size_t)idx * 2, 2))
+			return -1;
+		return be16(d + 20 + (size_t)idx * 2);
+	}
+	case 12:
+	case 13: {
+		if (len < 16)
+			return -1;
+		uint32_t n = be32(d + 12);
+		if (!rd_ok(len, 16, (size_t)n * 12))
+			return -1;
+		size_t lo = 0, hi = n;
+		while (lo < hi) { /* binary_search_by on [start,end] ranges */
+			size_t mid = lo + (hi - lo) / 2;
+			const uint8_t *g = d + 16 + mid * 12;
+			uint32_t sc = be32(g), ec = be32(g + 4), sg = be32(g + 8);
+			if (sc > cp)
+				hi = mid;
+			else if (ec < cp)
+				lo = mid + 1;
+			else {
+				uint64_t id = s->format == 12 ? (uint64_t)sg + cp - sc : sg;
+				if (s->format == 12 && (uint64_t)sg + cp > 0xFFFFFFFFull)
+					return -1;
+				return id > 0xFFFF ? -1 : (int)id;
+			}
+		}
+		return -1;
+	}
+	default:
+		return -1; /* formats 2, 8, 14: not restated (absent from all fixtures) */
+	}
+}
+
+typedef void (*cp_fn)(uint32_t cp, void *ctx);
+
+/* cmap Subtable::codepoints */
+static void sub_codepoints(const cmap_sub *s, cp_fn fn, void *ctx)
+{
+	const uint8_t *d = s->d.p;
+	size_t len = s->d.len;
+	switch (s->format) {
+	case 0:
+		if (len < 6 + 256)
+			return;
+		for (uint32_t i = 0; i < 256; i++)
+			if (d[6 + i] != 0)
+				fn(i, ctx);
+		return;
+	case 4: {
+		if (len < 16)
+			return;
+		unsigned segx2 = be16(d + 6);
+		if (segx2 < 2)
+			return;
+		size_t seg = segx2 / 2, end_off = 14, start_off = end_off + seg * 2 + 2;
+		if (!rd_ok(len, start_off + seg * 4, seg * 2))
+			return;
+		for (size_t i = 0; i < seg; i++) {
+			uint32_t st = be16(d + start_off + i * 2), en = be16(d + end_off + i * 2);
+			if (st == en && st == 0xFFFF)
+				break;
+			for (uint32_t c = st; c <= en; c++)
+				fn(c, ctx);
+		}
+		return;
+	}
+	case 6: {
+		if (len < 10)
+			return;
+		uint32_t first = be16(d + 6), count = be16(d + 8);
+		for (uint32_t i = 0; i < count && first + i <= 0xFFFF; i++)
+			fn(first + i, ctx);
+		return;
+	}
+	case 10: {
+		if (len < 20)
+			return;
+		uint32_t first = be32(d + 12), count = be32(d + 16);
+		for (uint32_t i = 0; i < count && first + i >= first; i++)
+			fn(first + i, ctx);
+		return;
+	}
+	case 12:
+	case 13: {
+		if (len < 16)
+			return;
+		uint32_t n = be32(d + 12);
+		if (!rd_ok(len, 16, (size_t)n * 12))
+			return;
+		for (uint32_t i = 0; i < n; i++) {
+			const uint8_t *g = d + 16 + (size_t)i * 12;
+			uint32_t sc = be32(g), ec = be32(g + 4);
+			for (uint64_t c = sc; c <= ec; c++)
+				fn((uint32_t)c, ctx);
+		}
+		return;
+	}
+	default:
+		return;
+	}
+}
+
+/* Face::glyph_index: first unicode subtable that maps the code point */
+int vgo_font_glyph_index(const vgo_font *f, uint32_t cp)
+{
+	cmap_sub s;
+	for (int i = 0; cmap_subtable(f, i, &s); i++) {
+		if (s.format < 0 || !sub_is_unicode(&s))
+			continue;
+		int g = sub_glyph_index(&s, cp);
+		if (g >= 0)
+			return g;
+	}
+	return -1;
+}
+
+typedef struct {
+	const cmap_sub *s;
+	uint8_t *bits; /* 0x110000 bits */
+} cp_ctx;
+
+static void cp_mark(uint32_t cp, void *vctx)
+{
+	cp_ctx *c = (cp_ctx *)vctx;
+	if (cp >= 0x110000)
+		return;
+	if (sub_glyph_index(c->s, cp) >= 0) /* metadata.rs:111-113 */
+		c->bits[cp >> 3] |= (uint8_t)(1u << (cp & 7));
+}
+
+/* FontMetadata::try_from, code point collection (metadata.rs:105-119) */
+int vgo_font_codepoints(const vgo_font *f, uint32_t *out, int cap)
+{
+	uint8_t *bits = (uint8_t *)calloc(0x110000 / 8, 1);
+	cmap_sub s;
+	for (int i = 0; cmap_subtable(f, i, &s); i++) {
+		if (s.format < 0 || !sub_is_unicode(&s))
+			continue;
+		cp_ctx c = {&s, bits};
+		sub_codepoints(&s, cp_mark, &c);
+	}
+	int n = 0;
+	for (uint32_t cp = 0; cp < 0x110000; cp++)
+		if (bits[cp >> 3] & (1u << (cp & 7))) {
+			if (out && n < cap)
+				out[n] = cp;
+			n++;
+		}
+	free(bits);
+	return n;
+}
+
+/* ------------------------------------------------------------------------------------
+ * glyf outline emission (ttf-parser tables/glyf.rs; call site renderer.rs:110)
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	vgo_cmd *out;
+	int cap, n;
+} cmd_sink;
+
+static void emit(cmd_sink *k, int kind, float x1, float y1, float x, float y)
+{
+	if (k->n < k->cap) {
+		vgo_cmd *c = &k->out[k->n];
+		c->kind = kind;
+		c->x1 = x1;
+		c->y1 = y1;
+		c->x2 = 0;
+		c->y2 = 0;
+		c->x = x;
+		c->y = y;
+	}
+	k->n++;
+}
+
+typedef struct {
+	float a, b, c, d, e, f;
+} xform;
+
+static const xform XF_ID = {1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+
+static int xf_is_default(const xform *t)
+{
+	return t->a == 1.0f && t->b == 0.0f && t->c == 0.0f && t->d == 1.0f && t->e == 0.0f &&
+	       t->f == 0.0f;
+}
+
+/* Transform::combine — f32, each op rounded (no contraction) */
+static xform xf_combine(xform t1, xform t2)
+{
+	xform r;
+	r.a = t1.a * t2.a + t1.c * t2.b;
+	r.b = t1.b * t2.a + t1.d * t2.b;
+	r.c = t1.a * t2.c + t1.c * t2.d;
+	r.d = t1.b * t2.c + t1.d * t2.d;
+	r.e = t1.a * t2.e + t1.c * t2.f + t1.e;
+	r.f = t1.b * t2.e + t1.d * t2.f + t1.f;
+	return r;
+}
+
+static void xf_apply(const xform *t, float *x, float *y)
+{
+	float tx = *x, ty = *y;
+	*x = t->a * tx + t->c * ty + t->e;
+	*y = t->b * tx + t->d * ty + t->f;
+}
+
+typedef struct {
+	cmd_sink *sink;
+	xform t;
+	int has_first_on, has_first_off, has_last_off;
+	float fon_x, fon_y, foff_x, foff_y, loff_x, loff_y;
+} builder;
+
+static void b_move(builder *b, float x, float y)
+{
+	if (!xf_is_default(&b->t))
+		xf_apply(&b->t, &x, &y);
+	emit(b->sink, VGO_MOVE, 0, 0, x, y);
+}
+static void b_line(builder *b, float x, float y)
+{
+	if (!xf_is_default(&b->t))
+		xf_apply(&b->t, &x, &y);
+	emit(b->sink, VGO_LINE, 0, 0, x, y);
+}
+static void b_quad(builder *b, float x1, float y1, float x, float y)
+{
+	if (!xf_is_default(&b->t)) {
+		xf_apply(&b->t, &x1, &y1);
+		xf_apply(&b->t, &x, &y);
+	}
+	emit(b->sink, VGO_QUAD, x1, y1, x, y);
+}
+
+/* Point::lerp(other, t) = self + t*(other - self), f32 */
+static inline float lerp_half(float a, float b) { return a + 0.5f * (b - a); }
+
+/* glyf.rs Builder::push_point / finish_contour */
+static void b_push_point(builder *b, float x, float y, int on_curve, int last)
+{
+	if (!b->has_first_on) {
+		if (on_curve) {
+			b->has_first_on = 1;
+			b->fon_x = x;
+			b->fon_y = y;
+			b_move(b, x, y);
+		} else if (b->has_first_off) {
+			float mx = lerp_half(b->foff_x, x), my = lerp_half(b->foff_y, y);
+			b->has_first_on = 1;
+			b->fon_x = mx;
+			b->fon_y = my;
+			b->has_last_off = 1;
+			b->loff_x = x;
+			b->loff_y = y;
+			b_move(b, mx, my);
+		} else {
+			b->has_first_off = 1;
+			b->foff_x = x;
+			b->foff_y = y;
+		}
+	} else if (b->has_last_off && on_curve) {
+		b->has_last_off = 0;
+		b_quad(b, b->loff_x, b->loff_y, x, y);
+	} else if (b->has_last_off && !on_curve) {
+		float ox = b->loff_x, oy = b->loff_y;
+		b->loff_x = x;
+		b->loff_y = y;
+		b_quad(b, ox, oy, lerp_half(ox, x), lerp_half(oy, y));
+	} else if (on_curve) {
+		b_line(b, x, y);
+	} else {
+		b->has_last_off = 1;
+		b->loff_x = x;
+		b->loff_y = y;
+	}
+
+	if (last) {
+		if (b->has_first_off && b->has_last_off) {
+			b->has_last_off = 0;
+			float mx = lerp_half(b->loff_x, b->foff_x), my = lerp_half(b->loff_y, b->foff_y);
+			b_quad(b, b->loff_x, b->loff_y, mx, my);
+		}
+		if (b->has_first_on && b->has_first_off)
+			b_quad(b, b->foff_x, b->foff_y, b->fon_x, b->fon_y);
+		else if (b->has_first_on && b->has_last_off)
+			b_quad(b, b->loff_x, b->loff_y, b->fon_x, b->fon_y);
+		else if (b->has_first_on)
+			b_line(b, b->fon_x, b->fon_y);
+		b->has_first_on = b->has_first_off = b->has_last_off = 0;
+		emit(b->sink, VGO_CLOSE, 0, 0, 0, 0);
+	}
+}
+
+/* loca.rs glyph_range + glyf.rs get */
+static int glyph_data(const vgo_font *f, int gid, span *out)
+{
+	if (!f->loca.p || !f->glyf.p || gid < 0 || gid == 0xFFFF)
+		return 0;
+	if ((size_t)gid + 1 >= f->loca_count)
+		return 0;
+	size_t a, b;
+	if (f->loca_long) {
+		a = be32(f->loca.p + (size_t)gid * 4);
+		b = be32(f->loca.p + (size_t)gid * 4 + 4);
+	} else {
+		a = (size_t)be16(f->loca.p + (size_t)gid * 2) * 2;
+		b = (size_t)be16(f->loca.p + (size_t)gid * 2 + 2) * 2;
+	}
+	if (a >= b || b > f->glyf.len)
+		return 0;
+	out->p = f->glyf.p + a;
+	out->len = b - a;
+	return 1;
+}
+
+/* glyf.rs parse_simple_outline + GlyphPointsIter; returns 0 on parse failure (abort) */
+static int simple_outline(span g, int n_contours, builder *b)
+{
+	const uint8_t *d = g.p;
+	size_t len = g.len, off = 0;
+	if (!rd_ok(len, off, (size_t)n_contours * 2))
+		return 0;
+	const uint8_t *endpts = d;
+	off += (size_t)n_contours * 2;
+	unsigned last_end = be16(endpts + ((size_t)n_contours - 1) * 2);
+	if (last_end == 0xFFFF)
+		return 0; /* checked_add(1) */
+	unsigned total = last_end + 1;
+	if (total == 1)
+		return 1; /* single point: empty iterator */
+	if (!rd_ok(len, off, 2))
+		return 0;
+	unsigned ilen = be16(d + off);
+	off += 2 + ilen; /* s.advance never fails; later reads do */
+	if (off > len)
+		return 0;
+	/* resolve_coords_len */
+	size_t flags_off = off, p = off;
+	unsigned left = total;
+	size_t xlen = 0, ylen = 0;
+	while (left > 0) {
+		if (!rd_ok(len, p, 1))
+			return 0;
+		uint8_t fl = d[p++];
+		unsigned rep = 1;
+		if (fl & 0x08) {
+			if (!rd_ok(len, p, 1))
+				return 0;
+			rep = (unsigned)d[p++] + 1;
+		}
+		if (rep > left)
+			return 0;
+		if (fl & 0x02)
+			xlen += rep;
+		else if (!(fl & 0x10))
+			xlen += (size_t)rep * 2;
+		if (fl & 0x04)
+			ylen += rep;
+		else if (!(fl & 0x20))
+			ylen += (size_t)rep * 2;
+		left -= rep;
+	}
+	size_t x_off = p, y_off = x_off + xlen, y_end = y_off + ylen;
+	if (y_end > len)
+		return 0;
+	/* iterate points */
+	size_t fp = flags_off, xp = x_off, yp = y_off;
+	uint8_t fl = 0;
+	unsigned repeats = 0;
+	int16_t x = 0, y = 0;
+	/* EndpointsIter */
+	unsigned ep_index = 1;
+	unsigned ep_left = be16(endpts);
+	for (unsigned i = 0; i < total; i++) {
+		int last_point;
+		if (ep_left == 0) {
+			if (ep_index < (unsigned)n_contours) {
+				unsigned end = be16(endpts + (size_t)ep_index * 2);
+				unsigned prev = be16(endpts + (size_t)(ep_index - 1) * 2);
+				ep_left = end > prev ? end - prev : 0;
+				ep_left = ep_left > 0 ? ep_left - 1 : 0;
+			}
+			ep_index++;
+			last_point = 1;
+		} else {
+			ep_left--;
+			last_point = 0;
+		}
+		if (repeats == 0) {
+			fl = fp < x_off ? d[fp++] : 0;
+			if (fl & 0x08)
+				repeats = fp < x_off ? d[fp++] : 0;
+		} else {
+			repeats--;
+		}
+		int16_t dx = 0, dy = 0;
+		if (fl & 0x02) {
+			int v = xp < y_off ? d[xp++] : 0;
+			dx = (int16_t)((fl & 0x10) ? v : -v);
+		} else if (!(fl & 0x10)) {
+			if (xp + 2 <= y_off) {
+				dx = (int16_t)be16(d + xp);
+				xp += 2;
+			}
+		}
+		if (fl & 0x04) {
+			int v = yp < y_end ? d[yp++] : 0;
+			dy = (int16_t)((fl & 0x20) ? v : -v);
+		} else if (!(fl & 0x20)) {
+			if (yp + 2 <= y_end) {
+				dy = (int16_t)be16(d + yp);
+				yp += 2;
+			}
+		}
+		x = (int16_t)(x + dx); /* wrapping_add */
+		y = (int16_t)(y + dy);
+		b_push_point(b, (float)x, (float)y, fl & 0x01, last_point);
+	}
+	return 1;
+}
+
+/* glyf.rs outline_impl; returns 0 when ttf-parser would bail out with None */
+static int outline_impl(const vgo_font *f, span g, int depth, cmd_sink *sink, xform t)
+{
+	if (depth >= MAX_COMPONENTS)
+		return 0;
+	if (g.len < 2)
+		return 0;
+	int16_t nc = (int16_t)be16(g.p);
+	size_t off = 10; /* numberOfContours + bbox */
+	if (nc > 0) {
+		if (off > g.len)
+			return 0;
+		builder b;
+		memset(&b, 0, sizeof b);
+		b.sink = sink;
+		b.t = t;
+		span body = {g.p + off, g.len - off};
+		return simple_outline(body, nc, &b);
+	} else if (nc < 0) {
+		if (off > g.len)
+			return 0;
+		const uint8_t *d = g.p + off;
+		size_t len = g.len - off, p = 0;
+		for (;;) { /* CompositeGlyphIter */
+			if (!rd_ok(len, p, 4))
+				break;
+			unsigned flags = be16(d + p), cg = be16(d + p + 2);
+			p += 4;
+			xform ct = XF_ID;
+			if (flags & 0x0002) { /* ARGS_ARE_XY_VALUES */
+				if (flags & 0x0001) {
+					if (!rd_ok(len, p, 4))
+						break;
+					ct.e = (float)(int16_t)be16(d + p);
+					ct.f = (float)(int16_t)be16(d + p + 2);
+					p += 4;
+				} else {
+					if (!rd_ok(len, p, 2))
+						break;
+					ct.e = (float)(int8_t)d[p];
+					ct.f = (float)(int8_t)d[p + 1];
+					p += 2;
+				}
+			} /* point-matching args are NOT skipped by ttf-parser 0.25 (parity unpinned) */
+			if (flags & 0x0080) {
+				if (!rd_ok(len, p, 8))
+					break;
+				ct.a = (float)(int16_t)be16(d + p) / 16384.0f;
+				ct.b = (float)(int16_t)be16(d + p + 2) / 16384.0f;
+				ct.c = (float)(int16_t)be16(d + p + 4) / 16384.0f;
+				ct.d = (float)(int16_t)be16(d + p + 6) / 16384.0f;
+				p += 8;
+			} else if (flags & 0x0040) {
+				if (!rd_ok(len, p, 4))
+					break;
+				ct.a = (float)(int16_t)be16(d + p) / 16384.0f;
+				ct.d = (float)(int16_t)be16(d + p + 2) / 16384.0f;
+				p += 4;
+			} else if (flags & 0x0008) {
+				if (!rd_ok(len, p, 2))
+					break;
+				ct.a = (float)(int16_t)be16(d + p) / 16384.0f;
+				ct.d = ct.a;
+				p += 2;
+			}
+			int more = (flags & 0x0020) != 0;
+			span cgd;
+			if (glyph_data(f, (int)cg, &cgd)) {
+				if (!outline_impl(f, cgd, depth + 1, sink, xf_combine(t, ct)))
+					return 0;
+			}
+			if (!more)
+				break;
+		}
+		return 1;
+	}
+	return 1;
+}
+
+int vgo_font_outline(const vgo_font *f, int gid, vgo_cmd *out, int cap)
+{
+	cmd_sink sink = {out, cap, 0};
+	span g;
+	if (!glyph_data(f, gid, &g))
+		return 0;
+	outline_impl(f, g, 0, &sink, XF_ID);
+	return sink.n;
+}
+
+/* ------------------------------------------------------------------------------------
+ * RingBuilder + flattening (render/ring_builder.rs, geometry/ring.rs, geometry/point.rs)
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	double *pts; /* x,y interleaved */
+	int n, cap;
+} ptvec;
+
+static void pv_push(ptvec *v, double x, double y)
+{
+	if (v->n == v->cap) {
+		v->cap = v->cap ? v->cap * 2 : 256;
+		v->pts = (double *)realloc(v->pts, sizeof(double) * 2 * (size_t)v->cap);
+	}
+	v->pts[2 * v->n] = x;
+	v->pts[2 * v->n + 1] = y;
+	v->n++;
+}
+
+typedef struct {
+	ptvec all;      /* points of saved rings, concatenated */
+	int *ring_off;  /* n_rings+1 */
+	int n_rings, ring_cap;
+	ptvec ring;     /* the active ring */
+} ringset;
+
+/* ring_builder.rs:33-54 save_ring, ring.rs:53-63 close */
+static void save_ring(ringset *rs)
+{
+	ptvec *r = &rs->ring;
+	if (r->n < 3) {
+		r->n = 0;
+		return;
+	}
+	double fx = r->pts[0], fy = r->pts[1];
+	double lx = r->pts[2 * (r->n - 1)], ly = r->pts[2 * (r->n - 1) + 1];
+	if (fabs(fx - lx) > 2.220446049250313e-16 || fabs(fy - ly) > 2.220446049250313e-16)
+		pv_push(r, fx, fy);
+	if (r->n < 4) {
+		r->n = 0;
+		return;
+	}
+	if (rs->n_rings + 2 > rs->ring_cap) {
+		rs->ring_cap = rs->ring_cap ? rs->ring_cap * 2 : 16;
+		rs->ring_off = (int *)realloc(rs->ring_off, sizeof(int) * (size_t)rs->ring_cap);
+	}
+	if (rs->n_rings == 0)
+		rs->ring_off[0] = 0;
+	for (int i = 0; i < r->n; i++)
+		pv_push(&rs->all, r->pts[2 * i], r->pts[2 * i + 1]);
+	rs->n_rings++;
+	rs->ring_off[rs->n_rings] = rs->all.n;
+	r->n = 0;
+}
+
+typedef struct {
+	double sx, sy, cx, cy, ex, ey;
+} quad;
+typedef struct {
+	double sx, sy, ax, ay, bx, by, ex, ey;
+} cubic;
+
+/* ring.rs:119-144 add_quadratic_bezier — explicit LIFO stack, right half pushed first */
+static void add_quad(ptvec *r, double sx, double sy, double cx, double cy, double ex, double ey,
+                     double tol_sq)
+{
+	int cap = 64, n = 0;
+	quad *st = (quad *)malloc(sizeof(quad) * (size_t)cap);
+	st[n++] = (quad){sx, sy, cx, cy, ex, ey};
+	while (n > 0) {
+		quad q = st[--n];
+		double dx = q.sx + q.ex - q.cx * 2.0;
+		double dy = q.sy + q.ey - q.cy * 2.0;
+		if (dx * dx + dy * dy <= tol_sq) {
+			pv_push(r, q.ex, q.ey);
+			continue;
+		}
+		double m1x = (q.sx + q.cx) / 2.0, m1y = (q.sy + q.cy) / 2.0; /* point.rs:29-31 */
+		double m2x = (q.cx + q.ex) / 2.0, m2y = (q.cy + q.ey) / 2.0;
+		double mx = (m1x + m2x) / 2.0, my = (m1y + m2y) / 2.0;
+		if (n + 2 > cap) {
+			cap *= 2;
+			st = (quad *)realloc(st, sizeof(quad) * (size_t)cap);
+		}
+		st[n++] = (quad){mx, my, m2x, m2y, q.ex, q.ey};
+		st[n++] = (quad){q.sx, q.sy, m1x, m1y, mx, my};
+	}
+	free(st);
+}
+
+/* ring.rs:159-187 add_cubic_bezier */
+static void add_cubic(ptvec *r, double sx, double sy, double ax, double ay, double bx, double by,
+                      double ex, double ey, double tol_sq)
+{
+	int cap = 64, n = 0;
+	cubic *st = (cubic *)malloc(sizeof(cubic) * (size_t)cap);
+	st[n++] = (cubic){sx, sy, ax, ay, bx, by, ex, ey};
+	while (n > 0) {
+		cubic c = st[--n];
+		double dx = (c.bx + c.ax) - (c.sx + c.ex);
+		double dy = (c.by + c.ay) - (c.sy + c.ey);
+		if (dx * dx + dy * dy <= tol_sq) {
+			pv_push(r, c.ex, c.ey);
+			continue;
+		}
+		double p01x = (c.sx + c.ax) / 2.0, p01y = (c.sy + c.ay) / 2.0;
+		double p12x = (c.ax + c.bx) / 2.0, p12y = (c.ay + c.by) / 2.0;
+		double p23x = (c.bx + c.ex) / 2.0, p23y = (c.by + c.ey) / 2.0;
+		double p012x = (p01x + p12x) / 2.0, p012y = (p01y + p12y) / 2.0;
+		double p123x = (p12x + p23x) / 2.0, p123y = (p12y + p23y) / 2.0;
+		double mx = (p012x + p123x) / 2.0, my = (p012y + p123y) / 2.0;
+		if (n + 2 > cap) {
+			cap *= 2;
+			st = (cubic *)realloc(st, sizeof(cubic) * (size_t)cap);
+		}
+		st[n++] = (cubic){mx, my, p123x, p123y, p23x, p23y, c.ex, c.ey};
+		st[n++] = (cubic){c.sx, c.sy, p01x, p01y, p012x, p012y, mx, my};
+	}
+	free(st);
+}
+
+/* ring_builder.rs:67-117 (OutlineBuilder impl) + :26-29 into_rings */
+static void build_rings(const vgo_cmd *cmds, int n_cmds, ringset *rs)
+{
+	const double precision = 0.01; /* ring_builder.rs:62 — used as tolerance_sq */
+	memset(rs, 0, sizeof *rs);
+	for (int i = 0; i < n_cmds; i++) {
+		const vgo_cmd *c = &cmds[i];
+		switch (c->kind) {
+		case VGO_MOVE:
+			save_ring(rs);
+			pv_push(&rs->ring, (double)c->x, (double)c->y);
+			break;
+		case VGO_LINE:
+			pv_push(&rs->ring, (double)c->x, (double)c->y);
+			break;
+		case VGO_QUAD:
+			if (rs->ring.n == 0)
+				break;
+			add_quad(&rs->ring, rs->ring.pts[2 * (rs->ring.n - 1)],
+			         rs->ring.pts[2 * (rs->ring.n - 1) + 1], (double)c->x1, (double)c->y1,
+			         (double)c->x, (double)c->y, precision);
+			break;
+		case VGO_CURVE:
+			if (rs->ring.n == 0)
+				break;
+			add_cubic(&rs->ring, rs->ring.pts[2 * (rs->ring.n - 1)],
+			          rs->ring.pts[2 * (rs->ring.n - 1) + 1], (double)c->x1, (double)c->y1,
+			          (double)c->x2, (double)c->y2, (double)c->x, (double)c->y, precision);
+			break;
+		case VGO_CLOSE:
+			save_ring(rs);
+			break;
+		}
+	}
+	save_ring(rs); /* into_rings */
+}
+
+static void ringset_free(ringset *rs)
+{
+	free(rs->all.pts);
+	free(rs->ring.pts);
+	free(rs->ring_off);
+}
+
+int vgo_build_rings(const vgo_cmd *cmds, int n_cmds, double *pts, int pts_cap, int *ring_off,
+                    int ring_cap, int *n_pts_out)
+{
+	ringset rs;
+	build_rings(cmds, n_cmds, &rs);
+	int ret = rs.n_rings;
+	if (n_pts_out)
+		*n_pts_out = rs.all.n;
+	if (rs.all.n > pts_cap || rs.n_rings + 1 > ring_cap) {
+		ret = -(rs.all.n > 0 ? rs.all.n : 1);
+	} else {
+		memcpy(pts, rs.all.pts, sizeof(double) * 2 * (size_t)rs.all.n);
+		if (rs.n_rings == 0)
+			ring_off[0] = 0;
+		else
+			memcpy(ring_off, rs.ring_off, sizeof(int) * (size_t)(rs.n_rings + 1));
+	}
+	ringset_free(&rs);
+	return ret;
+}
+
+/* Rust `f as i32`: truncate toward zero, saturating, NaN -> 0 */
+static int32_t f64_as_i32(double v)
+{
+	if (v != v)
+		return 0;
+	if (v >= 2147483647.0)
+		return INT32_MAX;
+	if (v <= -2147483648.0)
+		return INT32_MIN;
+	return (int32_t)v;
+}
+static uint32_t f64_as_u32(double v)
+{
+	if (v != v || v <= 0.0)
+		return 0;
+	if (v >= 4294967295.0)
+		return UINT32_MAX;
+	return (uint32_t)v;
+}
+
+/* Renderer::render_glyph up to and including prepare_glyph (renderer.rs:103-137, 64-91).
+ * On has_bitmap the scaled+shifted ring points stay in *rs_out for the caller. */
+static int prepare(const vgo_font *f, uint32_t cp, vgo_glyph_info *info, ringset *rs_out)
+{
+	memset(info, 0, sizeof *info);
+	memset(rs_out, 0, sizeof *rs_out);
+	info->id = cp;
+	if (cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) /* char::from_u32 (:104) */
+		return 0;
+	int gid = vgo_font_glyph_index(f, cp); /* :106 */
+	if (gid < 0)
+		return 0;
+	double scale = (double)GLYPH_SIZE / (double)f->units_per_em; /* :107 */
+
+	int ncmd = vgo_font_outline(f, gid, NULL, 0);
+	vgo_cmd *cmds = (vgo_cmd *)malloc(sizeof(vgo_cmd) * (size_t)(ncmd ? ncmd : 1));
+	vgo_font_outline(f, gid, cmds, ncmd);
+	build_rings(cmds, ncmd, rs_out); /* :109-111 */
+	free(cmds);
+
+	int adv = vgo_font_hor_advance(f, gid);
+	if (adv < 0)
+		adv = 0;
+	double advance_float = (double)adv * scale * 0.95; /* :115, left to right */
+	uint32_t advance = f64_as_u32(round(advance_float)); /* :116 */
+	info->advance = advance;
+
+	if (rs_out->n_rings == 0) /* :118-120 */
+		return 1;
+
+	double *p = rs_out->all.pts;
+	int np = rs_out->all.n;
+	for (int i = 0; i < np; i++) { /* :122 rings.scale (point.rs:96-99) */
+		p[2 * i] *= scale;
+		p[2 * i + 1] *= scale;
+	}
+	double dx = ((double)advance - advance_float) / 2.0; /* :130 */
+	for (int i = 0; i < np; i++) {                       /* :131 translate (point.rs:83-86) */
+		p[2 * i] += dx;
+		p[2 * i + 1] += 0.0;
+	}
+	/* prepare_glyph (:64-91); bbox.rs:26-31,56-58,64-69 */
+	double minx = INFINITY, miny = INFINITY, maxx = -INFINITY, maxy = -INFINITY;
+	for (int i = 0; i < np; i++) {
+		minx = fmin(minx, p[2 * i]);
+		miny = fmin(miny, p[2 * i + 1]);
+		maxx = fmax(maxx, p[2 * i]);
+		maxy = fmax(maxy, p[2 * i + 1]);
+	}
+	if (maxx <= minx && maxy <= miny)
+		return 1; /* PbfGlyph::empty */
+	int32_t x0 = f64_as_i32(floor(minx)) - BUFFER;
+	int32_t y0 = f64_as_i32(floor(miny)) - BUFFER;
+	int32_t x1 = f64_as_i32(ceil(maxx)) + BUFFER;
+	int32_t y1 = f64_as_i32(ceil(maxy)) + BUFFER;
+	info->x0 = x0;
+	info->y0 = y0;
+	info->w = (uint32_t)(x1 - x0);
+	info->h = (uint32_t)(y1 - y0);
+	info->has_bitmap = 1;
+	int nseg = 0;
+	for (int r = 0; r < rs_out->n_rings; r++)
+		nseg += rs_out->ring_off[r + 1] - rs_out->ring_off[r] - 1;
+	info->n_segments = nseg;
+	/* :146 y1 -= 24; result.rs:66-76 into_pbf_glyph */
+	y1 -= GLYPH_SIZE;
+	info->width = info->w - 2 * BUFFER;
+	info->height = info->h - 2 * BUFFER;
+	info->left = x0 + BUFFER;
+	info->top = y1 - BUFFER;
+	return 1;
+}
+
+/* Rings::get_segments (rings.rs:75-81, ring.rs:97-104) -> AoS sx,sy,ex,ey */
+static void rings_segments(const ringset *rs, double *segs)
+{
+	int k = 0;
+	for (int r = 0; r < rs->n_rings; r++)
+		for (int i = rs->ring_off[r]; i + 1 < rs->ring_off[r + 1]; i++) {
+			segs[4 * k] = rs->all.pts[2 * i];
+			segs[4 * k + 1] = rs->all.pts[2 * i + 1];
+			segs[4 * k + 2] = rs->all.pts[2 * i + 2];
+			segs[4 * k + 3] = rs->all.pts[2 * i + 3];
+			k++;
+		}
+}
+
+int vgo_prepare_glyph(const vgo_font *f, uint32_t cp, vgo_glyph_info *info, double *segs,
+                      int seg_cap)
+{
+	ringset rs;
+	int some = prepare(f, cp, info, &rs);
+	if (some && info->has_bitmap && segs && info->n_segments <= seg_cap)
+		rings_segments(&rs, segs);
+	ringset_free(&rs);
+	return some;
+}
+
+/* ------------------------------------------------------------------------------------
+ * the SDF raster
+ * ---------------------------------------------------------------------------------- */
+
+/* Segment::squared_distance_to_point (segment.rs:54-72,96-99; point.rs:38-42) */
+static inline double seg_dist_sq(double vx, double vy, double wx, double wy, double px, double py)
+{
+	double dx = wx - vx, dy = wy - vy;
+	double l2 = dx * dx + dy * dy;
+	double qx, qy;
+	if (l2 == 0.0) {
+		qx = vx;
+		qy = vy;
+	} else {
+		double t = ((px - vx) * (wx - vx) + (py - vy) * (wy - vy)) / l2;
+		if (t < 0.0) {
+			qx = vx;
+			qy = vy;
+		} else if (t > 1.0) {
+			qx = wx;
+			qy = wy;
+		} else {
+			qx = vx + t * (wx - vx);
+			qy = vy + t * (wy - vy);
+		}
+	}
+	double ex = qx - px, ey = qy - py; /* p.squared_distance_to(&proj): other - self */
+	return ex * ex + ey * ey;
+}
+
+typedef struct {
+	double x;
+	int sign;
+} crossing;
+
+static int cmp_crossing(const void *a, const void *b)
+{
+	double xa = ((const crossing *)a)->x, xb = ((const crossing *)b)->x;
+	return (xa > xb) - (xa < xb);
+}
+
+/* renderer_precise (renderer_precise.rs:8-84) + min_distance_to_line_segment
+ * (rtree_segments.rs:40-68).  mode VGO_PRECISE applies the R-tree's candidate rule
+ * (segment AABB intersects the closed box [p-8, p+8]^2, rtree_segments.rs:25-31,47-53);
+ * VGO_BRUTE takes the min over all segments. */
+void vgo_sdf_render(const double *segs, int n, int x0i, int y0i, int w, int h, int mode,
+                    uint8_t *out)
+{
+	if (mode == VGO_DUMMY) { /* renderer_dummy.rs:3-5 */
+		memset(out, 0, (size_t)w * (size_t)h);
+		return;
+	}
+	const double radius_by_256 = 256.0 / SDF_RADIUS; /* :25 */
+	const double x0 = (double)x0i + 0.5, y0 = (double)y0i + 0.5; /* :27-28 */
+	crossing *cr = (crossing *)malloc(sizeof(crossing) * (size_t)(n ? n : 1));
+	double *aabb = NULL;
+	if (mode == VGO_PRECISE) {
+		aabb = (double *)malloc(sizeof(double) * 4 * (size_t)(n ? n : 1));
+		for (int i = 0; i < n; i++) {
+			const double *s = segs + 4 * i;
+			aabb[4 * i] = fmin(s[0], s[2]);
+			aabb[4 * i + 1] = fmin(s[1], s[3]);
+			aabb[4 * i + 2] = fmax(s[0], s[2]);
+			aabb[4 * i + 3] = fmax(s[1], s[3]);
+		}
+	}
+	for (int y = 0; y < h; y++) {
+		double py = (double)y + y0; /* :34 */
+		int nc = 0;
+		for (int i = 0; i < n; i++) { /* :41-51 */
+			double sx = segs[4 * i], sy = segs[4 * i + 1], ex = segs[4 * i + 2],
+			       ey = segs[4 * i + 3];
+			if (sy <= py && ey > py) {
+				double t = (py - sy) / (ey - sy);
+				cr[nc].x = sx + t * (ex - sx);
+				cr[nc++].sign = 1;
+			} else if (sy > py && ey <= py) {
+				double t = (py - sy) / (ey - sy);
+				cr[nc].x = sx + t * (ex - sx);
+				cr[nc++].sign = -1;
+			}
+		}
+		qsort(cr, (size_t)nc, sizeof(crossing), cmp_crossing); /* :52 */
+		int wn = 0, idx = 0;
+		for (int x = 0; x < w; x++) {
+			double px = (double)x + x0; /* :62 */
+			while (idx < nc && cr[idx].x <= px) { /* :63-66 */
+				wn -= cr[idx].sign;
+				idx++;
+			}
+			int inside = wn != 0;
+			double best = INFINITY;
+			if (mode == VGO_PRECISE) {
+				double qx0 = px - SDF_RADIUS, qx1 = px + SDF_RADIUS;
+				double qy0 = py - SDF_RADIUS, qy1 = py + SDF_RADIUS;
+				for (int i = 0; i < n; i++) {
+					const double *a = aabb + 4 * i;
+					if (a[0] <= qx1 && a[2] >= qx0 && a[1] <= qy1 && a[3] >= qy0) {
+						const double *s = segs + 4 * i;
+						double d2 = seg_dist_sq(s[0], s[1], s[2], s[3], px, py);
+						if (d2 < best)
+							best = d2;
+					}
+				}
+			} else {
+				for (int i = 0; i < n; i++) {
+					const double *s = segs + 4 * i;
+					double d2 = seg_dist_sq(s[0], s[1], s[2], s[3], px, py);
+					if (d2 < best)
+						best = d2;
+				}
+			}
+			double d = sqrt(best); /* rtree_segments.rs:67 */
+			if (inside)
+				d = -d;
+			d = d * radius_by_256 + CUTOFF; /* :75 */
+			double nn = 255.0 - d;          /* :76 clamp(0,255) */
+			if (nn < 0.0)
+				nn = 0.0;
+			if (nn > 255.0)
+				nn = 255.0;
+			out[(size_t)(h - 1 - y) * (size_t)w + (size_t)x] = (uint8_t)round(nn); /* :78-79 */
+		}
+	}
+	free(cr);
+	free(aabb);
+}
+
+int vgo_render_glyph(const vgo_font *f, uint32_t cp, int mode, vgo_glyph_info *info,
+                     uint8_t *bitmap, size_t cap)
+{
+	ringset rs;
+	int some = prepare(f, cp, info, &rs);
+	int ret = some;
+	if (some && info->has_bitmap) {
+		size_t need = (size_t)info->w * info->h;
+		if (need > cap) {
+			ret = -1;
+		} else {
+			double *segs = (double *)malloc(sizeof(double) * 4 * (size_t)(info->n_segments + 1));
+			rings_segments(&rs, segs);
+			vgo_sdf_render(segs, info->n_segments, info->x0, info->y0, (int)info->w,
+			               (int)info->h, mode, bitmap);
+			free(segs);
+		}
+	}
+	ringset_free(&rs);
+	return ret;
+}
+
+/* ------------------------------------------------------------------------------------
+ * PBF encoding (prost derives at protobuf/glyph.rs:10-41, fontstack.rs:9-25,
+ * glyphs.rs:11-16)
+ * ---------------------------------------------------------------------------------- */
+static size_t varint_len(uint64_t v)
+{
+	size_t n = 1;
+	while (v >= 0x80) {
+		v >>= 7;
+		n++;
+	}
+	return n;
+}
+static uint8_t *put_varint(uint8_t *p, uint64_t v)
+{
+	while (v >= 0x80) {
+		*p++ = (uint8_t)(v | 0x80);
+		v >>= 7;
+	}
+	*p++ = (uint8_t)v;
+	return p;
+}
+static inline uint32_t zigzag32(int32_t v) { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); }
+
+static size_t glyph_body_len(const vgo_glyph_info *g)
+{
+	size_t n = 1 + varint_len(g->id);
+	if (g->has_bitmap) {
+		size_t bl = (size_t)g->w * g->h;
+		n += 1 + varint_len(bl) + bl;
+	}
+	n += 1 + varint_len(g->width) + 1 + varint_len(g->height);
+	n += 1 + varint_len(zigzag32(g->left)) + 1 + varint_len(zigzag32(g->top));
+	n += 1 + varint_len(g->advance);
+	return n;
+}
+
+size_t vgo_pbf_encode(const char *name, uint32_t start, const vgo_glyph_info *glyphs,
+                      const uint8_t *const *bitmaps, int n, uint8_t *out, size_t cap)
+{
+	char range[32];
+	snprintf(range, sizeof range, "%u-%u", start, start + 255); /* glyph_block.rs:53-59 */
+	size_t nl = strlen(name), rl = strlen(range);
+	size_t stack = 1 + varint_len(nl) + nl + 1 + varint_len(rl) + rl;
+	for (int i = 0; i < n; i++) {
+		size_t gl = glyph_body_len(&glyphs[i]);
+		stack += 1 + varint_len(gl) + gl;
+	}
+	size_t total = 1 + varint_len(stack) + stack;
+	if (total > cap || !out)
+		return total;
+	uint8_t *p = out;
+	*p++ = 0x0A;
+	p = put_varint(p, stack);
+	*p++ = 0x0A;
+	p = put_varint(p, nl);
+	memcpy(p, name, nl);
+	p += nl;
+	*p++ = 0x12;
+	p = put_varint(p, rl);
+	memcpy(p, range, rl);
+	p += rl;
+	for (int i = 0; i < n; i++) {
+		const vgo_glyph_info *g = &glyphs[i];
+		*p++ = 0x1A;
+		p = put_varint(p, glyph_body_len(g));
+		*p++ = 0x08;
+		p = put_varint(p, g->id);
+		if (g->has_bitmap) {
+			size_t bl = (size_t)g->w * g->h;
+			*p++ = 0x12;
+			p = put_varint(p, bl);
+			memcpy(p, bitmaps[i], bl);
+			p += bl;
+		}
+		*p++ = 0x18;
+		p = put_varint(p, g->width);
+		*p++ = 0x20;
+		p = put_varint(p, g->height);
+		*p++ = 0x28;
+		p = put_varint(p, zigzag32(g->left));
+		*p++ = 0x30;
+		p = put_varint(p, zigzag32(g->top));
+		*p++ = 0x38;
+		p = put_varint(p, g->advance);
+	}
+	return (size_t)(p - out);
+}
+
+/* ------------------------------------------------------------------------------------
+ * GlyphBlock::render / FontWrapper::get_blocks / FontManager::render_glyphs
+ * (font/glyph_block.rs:34-36,69-80; wrapper.rs:53-76; manager.rs:81-125)
+ * ---------------------------------------------------------------------------------- */
+
+/* provider[cp] = index of the first font (in precedence order) covering cp, or -1 */
+static int16_t *build_providers(const vgo_font *const *fonts, int n_fonts)
+{
+	int16_t *prov = (int16_t *)malloc(sizeof(int16_t) * 0x10000);
+	for (int i = 0; i < 0x10000; i++)
+		prov[i] = -1;
+	for (int fi = 0; fi < n_fonts; fi++) {
+		int n = vgo_font_codepoints(fonts[fi], NULL, 0);
+		uint32_t *cps = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+		vgo_font_codepoints(fonts[fi], cps, n);
+		for (int i = 0; i < n; i++)
+			if (cps[i] <= 0xFFFF && prov[cps[i]] < 0) /* wrapper.rs:66-71, glyph_block.rs:35 */
+				prov[cps[i]] = (int16_t)fi;
+		free(cps);
+	}
+	return prov;
+}
+
+static size_t render_block_prov(const vgo_font *const *fonts, const int16_t *prov,
+                                const char *name, uint32_t start, int mode, uint8_t **out,
+                                int *n_glyphs, uint64_t *n_pixels, uint64_t *n_segs)
+{
+	vgo_glyph_info infos[256];
+	uint8_t *bitmaps[256];
+	int n = 0;
+	uint64_t pix = 0, segs = 0;
+	for (uint32_t ci = 0; ci < 256; ci++) { /* canonical order: ascending id */
+		uint32_t cp = start + ci;
+		int fi = prov[cp];
+		if (fi < 0)
+			continue;
+		vgo_glyph_info info;
+		ringset rs;
+		int some = prepare(fonts[fi], cp, &info, &rs);
+		if (some) {
+			bitmaps[n] = NULL;
+			if (info.has_bitmap) {
+				size_t need = (size_t)info.w * info.h;
+				bitmaps[n] = (uint8_t *)malloc(need);
+				double *sg = (double *)malloc(sizeof(double) * 4 * (size_t)(info.n_segments + 1));
+				rings_segments(&rs, sg);
+				vgo_sdf_render(sg, info.n_segments, info.x0, info.y0, (int)info.w, (int)info.h,
+				               mode, bitmaps[n]);
+				free(sg);
+				pix += need;
+				segs += (uint64_t)info.n_segments;
+			}
+			infos[n++] = info;
+		}
+		ringset_free(&rs);
+	}
+	size_t need = vgo_pbf_encode(name, start, infos, (const uint8_t *const *)bitmaps, n, NULL, 0);
+	*out = (uint8_t *)malloc(need ? need : 1);
+	vgo_pbf_encode(name, start, infos, (const uint8_t *const *)bitmaps, n, *out, need);
+	int nb = 0;
+	for (int i = 0; i < n; i++) {
+		if (infos[i].has_bitmap)
+			nb++;
+		free(bitmaps[i]);
+	}
+	if (n_glyphs)
+		*n_glyphs = n;
+	if (n_pixels)
+		*n_pixels = pix;
+	if (n_segs)
+		*n_segs = segs;
+	(void)nb;
+	return need;
+}
+
+size_t vgo_render_block(const vgo_font *const *fonts, int n_fonts, const char *name,
+                        uint32_t start, int mode, uint8_t *out, size_t cap, int *n_glyphs,
+                        uint64_t *n_pixels)
+{
+	int16_t *prov = build_providers(fonts, n_fonts);
+	uint8_t *buf = NULL;
+	size_t need = render_block_prov(fonts, prov, name, start, mode, &buf, n_glyphs, n_pixels, NULL);
+	if (out && need <= cap)
+		memcpy(out, buf, need);
+	free(buf);
+	free(prov);
+	return need;
+}
+
+typedef struct {
+	const vgo_font *const *fonts;
+	const int16_t *prov;
+	const char *name;
+	int mode;
+	int only_block;
+	int next; /* block cursor, guarded by mu */
+	pthread_mutex_t mu;
+	uint64_t blocks, glyphs, pixels, segs, bytes;
+	uint64_t block_hash[256];
+} all_job;
+
+static uint64_t fnv1a(uint64_t h, const uint8_t *p, size_t n)
+{
+	for (size_t i = 0; i < n; i++) {
+		h ^= p[i];
+		h *= 0x100000001b3ull;
+	}
+	return h;
+}
+
+static void *all_worker(void *arg)
+{
+	all_job *j = (all_job *)arg;
+	for (;;) {
+		pthread_mutex_lock(&j->mu);
+		int b = j->next++;
+		pthread_mutex_unlock(&j->mu);
+		if (b >= 256)
+			break;
+		uint32_t start = (uint32_t)b * 256;
+		if (j->only_block >= 0 && (uint32_t)j->only_block != start)
+			continue;
+		uint8_t *buf = NULL;
+		int ng = 0;
+		uint64_t px = 0, sg = 0;
+		size_t len = render_block_prov(j->fonts, j->prov, j->name, start, j->mode, &buf, &ng, &px, &sg);
+		uint8_t st[4] = {(uint8_t)(start >> 24), (uint8_t)(start >> 16), (uint8_t)(start >> 8),
+		                 (uint8_t)start};
+		uint64_t h = fnv1a(0xcbf29ce484222325ull, st, 4);
+		h = fnv1a(h, buf, len);
+		free(buf);
+		pthread_mutex_lock(&j->mu); /* the writer mutex of manager.rs:108-111 */
+		j->blocks++;
+		j->glyphs += (uint64_t)ng;
+		j->pixels += px;
+		j->segs += sg;
+		j->bytes += len;
+		j->block_hash[b] = h;
+		pthread_mutex_unlock(&j->mu);
+	}
+	return NULL;
+}
+
+double vgo_render_all(const vgo_font *const *fonts, int n_fonts, const char *name, int mode,
+                      int threads, int only_block, uint64_t counters[6])
+{
+	all_job j;
+	memset(&j, 0, sizeof j);
+	j.fonts = fonts;
+	j.name = name;
+	j.mode = mode;
+	j.only_block = only_block;
+	pthread_mutex_init(&j.mu, NULL);
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	int16_t *prov = build_providers(fonts, n_fonts);
+	j.prov = prov;
+	if (threads < 1)
+		threads = 1;
+	if (threads > 256)
+		threads = 256;
+	pthread_t th[256];
+	for (int i = 0; i < threads; i++)
+		pthread_create(&th[i], NULL, all_worker, &j);
+	for (int i = 0; i < threads; i++)
+		pthread_join(th[i], NULL);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	free(prov);
+	pthread_mutex_destroy(&j.mu);
+	uint64_t h = 0xcbf29ce484222325ull;
+	for (int b = 0; b < 256; b++)
+		h = fnv1a(h, (const uint8_t *)&j.block_hash[b], 8);
+	if (counters) {
+		counters[0] = j.blocks;
+		counters[1] = j.glyphs;
+		counters[2] = j.pixels;
+		counters[3] = j.segs;
+		counters[4] = j.bytes;
+		counters[5] = h;
+	}
+	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

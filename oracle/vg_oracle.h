@@ -1,0 +1,115 @@
+/*
+ * vg_oracle.h — CPU ORACLE for the versatiles-glyphs SDF render path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C, scalar, f64 restatement of the
+ * reference algorithm (versatiles-glyphs-rs v0.9.1, /root/reference/src/render +
+ * src/geometry).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (versatiles-glyphs-rs_amd/) never
+ * links, imports or calls anything in oracle/.
+ *
+ * Parity pinning: the reference is Rust and cannot be built in this image (no
+ * rustc/cargo, no network), so the oracle is pinned by the reference's own
+ * known-answer tests — see tests/test_oracle_kat.py:
+ *   renderer_precise.rs:96-135 (digit-art square), renderer.rs:176-287
+ *   (Fira glyph 32/65/96/230 metrics + ASCII art), recurse.rs:341-367 (20 PBF
+ *   sizes), wrapper.rs:197-221 (block counts), metadata.rs:142,152 (1686/3094),
+ *   ring_builder.rs:197-229 (17-point flattening KATs).
+ * Third-party behaviour restated (not in /root/reference): ttf-parser 0.25.1
+ * (glyf outline emission, cmap 4/12, hmtx), rstar 0.13.0 (envelope filter only),
+ * prost 0.14.4 (proto2 wire encoding).
+ *
+ * Build with -ffp-contract=off: Rust never contracts a*b+c into an FMA.
+ */
+#ifndef VG_ORACLE_H
+#define VG_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vgo_font vgo_font;
+
+/* outline command stream as ttf_parser::OutlineBuilder receives it (f32, font units) */
+enum { VGO_MOVE = 0, VGO_LINE = 1, VGO_QUAD = 2, VGO_CURVE = 3, VGO_CLOSE = 4 };
+typedef struct {
+	int32_t kind;
+	float x1, y1; /* control point (quad) / first control (curve) */
+	float x2, y2; /* second control (curve only) */
+	float x, y;   /* end point */
+} vgo_cmd;
+
+/* one rendered glyph = PbfGlyph (protobuf/glyph.rs:10-41) + the raster rect */
+typedef struct {
+	uint32_t id;
+	int32_t has_bitmap;         /* bitmap: Option<Vec<u8>> is Some */
+	uint32_t width, height;     /* without the 2*3 px buffer */
+	int32_t left, top;
+	uint32_t advance;
+	int32_t x0, y0;             /* raster rect origin incl. -3 buffer (RenderResult.x0/y0) */
+	uint32_t w, h;              /* raster size incl. +6 (RenderResult.width/height) */
+	int32_t n_segments;
+} vgo_glyph_info;
+
+/* render modes (renderer.rs:140-143 has Precise|Dummy; BRUTE = Precise without the
+ * ±8 px R-tree envelope filter, results-identical in u8 — SURVEY §8(a)-9) */
+enum { VGO_PRECISE = 0, VGO_BRUTE = 1, VGO_DUMMY = 2 };
+
+/* ---- font access (restates the ttf_parser::Face calls made by the reference) ---- */
+vgo_font *vgo_font_open(const uint8_t *data, size_t len); /* copies data; NULL on parse failure */
+void vgo_font_close(vgo_font *f);
+int vgo_font_units_per_em(const vgo_font *f);
+int vgo_font_num_glyphs(const vgo_font *f);
+/* sorted unique code points covered by unicode cmap subtables (metadata.rs:105-117) */
+int vgo_font_codepoints(const vgo_font *f, uint32_t *out, int cap);
+int vgo_font_glyph_index(const vgo_font *f, uint32_t cp); /* -1 = None */
+int vgo_font_hor_advance(const vgo_font *f, int gid);     /* -1 = None */
+int vgo_font_outline(const vgo_font *f, int gid, vgo_cmd *out, int cap); /* returns #commands */
+
+/* ---- geometry ---- */
+/* RingBuilder (ring_builder.rs) over a command stream; writes closed rings' points
+ * (x,y interleaved, font units) and ring start offsets (n_rings+1). returns n_rings, or
+ * -(needed points) if pts_cap is too small. */
+int vgo_build_rings(const vgo_cmd *cmds, int n_cmds, double *pts, int pts_cap, int *ring_off,
+                    int ring_cap, int *n_pts_out);
+
+/* Renderer::render_glyph up to prepare_glyph (renderer.rs:103-137): returns 0 = None,
+ * 1 = Some.  info->has_bitmap tells whether a raster follows; segments (AoS sx,sy,ex,ey;
+ * scaled + shifted, Rings::get_segments order) are written when seg_cap suffices. */
+int vgo_prepare_glyph(const vgo_font *f, uint32_t cp, vgo_glyph_info *info, double *segs,
+                      int seg_cap);
+
+/* renderer_precise (renderer_precise.rs:8-84) on an explicit segment list */
+void vgo_sdf_render(const double *segs, int n, int x0, int y0, int w, int h, int mode,
+                    uint8_t *out);
+
+/* Renderer::render_glyph complete; bitmap must hold info->w*info->h bytes (call
+ * vgo_prepare_glyph first for sizes, or pass cap >= needed). returns 0 None, 1 Some,
+ * -1 cap too small */
+int vgo_render_glyph(const vgo_font *f, uint32_t cp, int mode, vgo_glyph_info *info,
+                     uint8_t *bitmap, size_t cap);
+
+/* ---- PBF (protobuf/ *.rs via prost) ---- */
+size_t vgo_pbf_encode(const char *name, uint32_t start, const vgo_glyph_info *glyphs,
+                      const uint8_t *const *bitmaps, int n, uint8_t *out, size_t cap);
+
+/* GlyphBlock::render (glyph_block.rs:69-80) in canonical form: glyphs ascending by id;
+ * fonts[] in precedence order, first provider of a code point wins (glyph_block.rs:35).
+ * returns encoded size (needed size if > cap). */
+size_t vgo_render_block(const vgo_font *const *fonts, int n_fonts, const char *name,
+                        uint32_t start, int mode, uint8_t *out, size_t cap, int *n_glyphs,
+                        uint64_t *n_pixels);
+
+/* FontManager::render_glyphs analogue used as the timed CPU baseline
+ * (manager.rs:81-125): all 256 BMP blocks, one task per block on `threads` workers.
+ * counters: [0]=blocks written, [1]=glyphs emitted (Some), [2]=pixels, [3]=segments,
+ * [4]=sum of encoded PBF bytes, [5]=FNV-1a over (start, pbf bytes) in block order.
+ * If only_block >= 0 render just that block start. returns wall seconds. */
+double vgo_render_all(const vgo_font *const *fonts, int n_fonts, const char *name, int mode,
+                      int threads, int only_block, uint64_t counters[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
