@@ -1,0 +1,116 @@
+/*
+ * vgsdf.h — C ABI of the MI355X SDF raster (libvgsdf.so).
+ *
+ * Drop-in boundary for the per-glyph hot loop of versatiles-glyphs-rs: one call renders
+ * the signed-distance bitmaps of a whole batch of glyphs on the GPU, bit-exact with
+ *   renderer_precise()               src/render/renderer_precise.rs:8-84
+ *   min_distance_to_line_segment()   src/render/rtree_segments.rs:40-68
+ *   Segment::squared_distance_to_point / project_point_on   src/geometry/segment.rs:54-99
+ * which the reference runs once per glyph from Renderer::render_glyph
+ * (src/render/renderer.rs:140-143, the `match self.mode` arm a new back-end slots into).
+ * The caller is the GPU batch dispatcher that replaces the rayon block loop of
+ * FontManager::render_glyphs (src/font/manager.rs:104-121); see vgfont.h.
+ *
+ * Plain C: pointers + sizes, no C++/torch types, no exceptions across the boundary.
+ * Every entry point returns VGSDF_OK (0) or a negative vgsdf_status; the message is
+ * available from vgsdf_last_error().  There is NO CPU fallback: without a usable HIP
+ * device vgsdf_create() fails with VGSDF_E_HIP.
+ *
+ * Reference-side binding (Rust `extern "C"` block, untested here — no rustc in this
+ * image): INTEGRATION.md.
+ */
+#ifndef VGSDF_H
+#define VGSDF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	VGSDF_OK = 0,
+	VGSDF_E_ARG = -1, /* NULL / inconsistent batch */
+	VGSDF_E_HIP = -2, /* HIP runtime error (no device, launch failure, ...) */
+	VGSDF_E_OOM = -3  /* device or pinned-host allocation failed */
+} vgsdf_status;
+
+/* One context per (host thread, GPU): owns a HIP stream, device buffers and pinned
+ * staging.  Not thread-safe; use one per thread. */
+typedef struct vgsdf_ctx vgsdf_ctx;
+/* A batch resident in HBM (segments, descriptors, tile list, output bitmaps). */
+typedef struct vgsdf_dbatch vgsdf_dbatch;
+
+/*
+ * Host-side SoA batch, caller-owned, read-only during the call.
+ *
+ * Segments are what Rings::get_segments() yields (src/geometry/rings.rs:75-81) AFTER
+ * rings.scale() and rings.translate() (renderer.rs:122,131): consecutive point pairs per
+ * ring, rings in order, f64 pixel units.  Glyph g owns segments
+ * [seg_off[g], seg_off[g+1]).  (x0,y0,w,h) is RenderResult{x0,y0,width,height}
+ * (src/render/result.rs:7-29), i.e. including the 3 px buffer on every side.
+ * Output bitmap of glyph g: out[out_off[g] + (h-1-y)*w + x], row-major, top row first —
+ * exactly renderer_precise.rs:78; out_off[g+1]-out_off[g] == w[g]*h[g].
+ */
+typedef struct {
+	uint32_t n_glyphs;
+	const uint32_t *seg_off; /* [n_glyphs+1] prefix sums */
+	const double *seg_sx;    /* [seg_off[n_glyphs]] */
+	const double *seg_sy;
+	const double *seg_ex;
+	const double *seg_ey;
+	const int32_t *x0; /* [n_glyphs] */
+	const int32_t *y0;
+	const uint32_t *w;
+	const uint32_t *h;
+	const uint64_t *out_off; /* [n_glyphs+1] prefix sums of w*h */
+} vgsdf_batch;
+
+/* Per-launch statistics (filled by vgsdf_batch_stats). */
+typedef struct {
+	uint64_t n_glyphs;
+	uint64_t n_segments;
+	uint64_t n_pixels;
+	uint64_t n_pairs;   /* sum over glyphs of w*h*n_segments (pixel x segment evaluations) */
+	uint64_t n_tiles;   /* workgroups launched */
+	uint64_t alg_bytes; /* 32*segments + 32*glyphs + pixels   */
+} vgsdf_stats;
+
+int vgsdf_device_count(void);
+int vgsdf_create(int device_ordinal, vgsdf_ctx **out);
+void vgsdf_destroy(vgsdf_ctx *ctx);
+const char *vgsdf_last_error(const vgsdf_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* Synchronous whole-batch render: H2D, kernel, D2H; out_bitmaps is host memory of
+ * out_off[n_glyphs] bytes. */
+int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitmaps);
+
+/* Split form, for callers that keep batches resident / overlap transfers:
+ *   upload   : validates, builds the tile list, copies everything to HBM (async on the
+ *              context stream, staged through pinned memory).
+ *   launch   : enqueues the SDF kernel on the context stream (asynchronous).
+ *   download : enqueues D2H of all bitmaps and waits for it.
+ *   sync     : waits for the context stream. */
+int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out);
+int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b);
+int vgsdf_batch_download(vgsdf_ctx *ctx, vgsdf_dbatch *b, uint8_t *out_bitmaps);
+int vgsdf_batch_free(vgsdf_ctx *ctx, vgsdf_dbatch *b);
+int vgsdf_sync(vgsdf_ctx *ctx);
+int vgsdf_batch_stats(const vgsdf_dbatch *b, vgsdf_stats *out);
+
+/* Times `iters` back-to-back launches of the SDF kernel with HIP events recorded on the
+ * context stream (the stream the kernel runs on); *total_ms = elapsed for all of them. */
+int vgsdf_batch_time(vgsdf_ctx *ctx, vgsdf_dbatch *b, int iters, float *total_ms);
+
+/* Selects the kernel variant: 0 = default (best verified), other values select
+ * alternative implementations for A/B measurements. */
+int vgsdf_set_variant(vgsdf_ctx *ctx, int variant);
+
+/* Raw device pointer of the resident output bitmaps (for zero-copy consumers on the same
+ * device, e.g. a torch tensor wrapping it); valid until vgsdf_batch_free. */
+void *vgsdf_batch_device_output(const vgsdf_dbatch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

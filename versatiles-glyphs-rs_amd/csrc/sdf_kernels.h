@@ -1,0 +1,27 @@
+// sdf_kernels.h — device-side data layout shared by the kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VGSDF_TILE_PIXELS 256
+
+namespace vgsdf {
+
+// One glyph's raster job, 32 bytes (the "+32 descriptor" of SURVEY.md §8d).
+// (x0,y0,w,h) = RenderResult{x0,y0,width,height}, /root/reference/src/render/result.rs:7-29.
+struct GlyphDesc {
+	uint32_t seg_off; // first segment in the SoA arrays
+	uint32_t n_seg;
+	int32_t x0, y0;
+	uint32_t w, h;
+	uint64_t out_off; // first byte of this glyph's bitmap in the output buffer
+};
+static_assert(sizeof(GlyphDesc) == 32, "GlyphDesc must stay 32 bytes");
+
+} // namespace vgsdf
+
+// tiles[i] = (glyph index, first output byte of the tile inside that glyph's bitmap)
+extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, const uint2 *tiles,
+                                  uint32_t n_tiles, const double *sx, const double *sy,
+                                  const double *ex, const double *ey, uint8_t *out,
+                                  hipStream_t stream);

@@ -1,0 +1,360 @@
+// vgsdf_device.cpp — C-ABI layer of libvgsdf.so (include/vgsdf.h): contexts, HBM-resident
+// batches, transfers and launches.  No CPU fallback lives here or anywhere in the
+// product: if HIP is unusable every entry point reports VGSDF_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vgsdf.h"
+#include "sdf_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+struct vgsdf_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	int variant = 0;
+	std::string err;
+};
+
+struct vgsdf_dbatch {
+	vgsdf_stats stats{};
+	// one device arena: [descs | tiles | sx | sy | ex | ey | out]
+	void *d_arena = nullptr;
+	size_t arena_bytes = 0, input_bytes = 0;
+	void *h_stage = nullptr; // pinned staging of the input part
+	vgsdf::GlyphDesc *d_glyphs = nullptr;
+	uint2 *d_tiles = nullptr;
+	double *d_sx = nullptr, *d_sy = nullptr, *d_ex = nullptr, *d_ey = nullptr;
+	uint8_t *d_out = nullptr;
+	size_t out_bytes = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+	do {                                                                                       \
+		hipError_t e__ = (expr);                                                               \
+		if (e__ != hipSuccess) {                                                               \
+			(ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+			return e__ == hipErrorOutOfMemory ? VGSDF_E_OOM : VGSDF_E_HIP;                     \
+		}                                                                                      \
+	} while (0)
+
+extern "C" {
+
+int vgsdf_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int vgsdf_create(int device_ordinal, vgsdf_ctx **out)
+{
+	if (!out) {
+		g_create_error = "vgsdf_create: out is NULL";
+		return VGSDF_E_ARG;
+	}
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		g_create_error = std::string("vgsdf_create: no HIP device (") +
+		                 (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+		                 "); this library has no CPU fallback";
+		return VGSDF_E_HIP;
+	}
+	if (device_ordinal < 0 || device_ordinal >= n) {
+		g_create_error = "vgsdf_create: device ordinal out of range";
+		return VGSDF_E_ARG;
+	}
+	vgsdf_ctx *ctx = new (std::nothrow) vgsdf_ctx();
+	if (!ctx) {
+		g_create_error = "vgsdf_create: out of host memory";
+		return VGSDF_E_OOM;
+	}
+	ctx->device = device_ordinal;
+	if ((e = hipSetDevice(device_ordinal)) != hipSuccess ||
+	    (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+		g_create_error = std::string("vgsdf_create: ") + hipGetErrorString(e);
+		vgsdf_destroy(ctx);
+		return VGSDF_E_HIP;
+	}
+	*out = ctx;
+	return VGSDF_OK;
+}
+
+void vgsdf_destroy(vgsdf_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) {
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipStreamDestroy(ctx->stream);
+	}
+	if (ctx->ev0)
+		(void)hipEventDestroy(ctx->ev0);
+	if (ctx->ev1)
+		(void)hipEventDestroy(ctx->ev1);
+	delete ctx;
+}
+
+const char *vgsdf_last_error(const vgsdf_ctx *ctx)
+{
+	return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int vgsdf_set_variant(vgsdf_ctx *ctx, int variant)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	ctx->variant = variant;
+	return VGSDF_OK;
+}
+
+int vgsdf_sync(vgsdf_ctx *ctx)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return VGSDF_OK;
+}
+
+int vgsdf_batch_free(vgsdf_ctx *ctx, vgsdf_dbatch *b)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!b)
+		return VGSDF_OK;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	if (b->d_arena)
+		(void)hipFree(b->d_arena);
+	if (b->h_stage)
+		(void)hipHostFree(b->h_stage);
+	delete b;
+	return VGSDF_OK;
+}
+
+int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!in || !out) {
+		ctx->err = "vgsdf_batch_upload: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	*out = nullptr;
+	const uint32_t n = in->n_glyphs;
+	if (n && (!in->seg_off || !in->x0 || !in->y0 || !in->w || !in->h || !in->out_off)) {
+		ctx->err = "vgsdf_batch_upload: NULL array in batch";
+		return VGSDF_E_ARG;
+	}
+	const uint64_t n_seg = n ? in->seg_off[n] : 0;
+	if (n_seg && (!in->seg_sx || !in->seg_sy || !in->seg_ex || !in->seg_ey)) {
+		ctx->err = "vgsdf_batch_upload: NULL segment array";
+		return VGSDF_E_ARG;
+	}
+	// validate shapes on the host BEFORE anything is launched: the kernel indexes with them
+	uint64_t n_tiles = 0, n_pairs = 0;
+	if (n && (in->seg_off[0] != 0 || in->out_off[0] != 0)) {
+		ctx->err = "vgsdf_batch_upload: seg_off[0] and out_off[0] must be 0";
+		return VGSDF_E_ARG;
+	}
+	for (uint32_t g = 0; g < n; g++) {
+		if (in->seg_off[g + 1] < in->seg_off[g]) {
+			ctx->err = "vgsdf_batch_upload: seg_off not monotone";
+			return VGSDF_E_ARG;
+		}
+		const uint64_t px = (uint64_t)in->w[g] * in->h[g];
+		if (px > 0xFFFFFFFFull - VGSDF_TILE_PIXELS || in->out_off[g + 1] - in->out_off[g] != px) {
+			ctx->err = "vgsdf_batch_upload: out_off inconsistent with w*h";
+			return VGSDF_E_ARG;
+		}
+		n_tiles += (px + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
+		n_pairs += px * (in->seg_off[g + 1] - in->seg_off[g]);
+	}
+	if (n_tiles > 0x7FFFFFFFull) {
+		ctx->err = "vgsdf_batch_upload: batch too large (tile count exceeds 2^31-1); split it";
+		return VGSDF_E_ARG;
+	}
+	const uint64_t n_pix = n ? in->out_off[n] : 0;
+
+	vgsdf_dbatch *b = new (std::nothrow) vgsdf_dbatch();
+	if (!b) {
+		ctx->err = "vgsdf_batch_upload: out of host memory";
+		return VGSDF_E_OOM;
+	}
+	b->stats.n_glyphs = n;
+	b->stats.n_segments = n_seg;
+	b->stats.n_pixels = n_pix;
+	b->stats.n_pairs = n_pairs;
+	b->stats.n_tiles = n_tiles;
+	b->stats.alg_bytes = 32 * n_seg + 32 * (uint64_t)n + n_pix;
+	b->out_bytes = n_pix;
+
+	const size_t A = 256;
+	size_t off = 0;
+	const size_t off_desc = off;
+	off = align_up(off + sizeof(vgsdf::GlyphDesc) * (size_t)n, A);
+	const size_t off_tiles = off;
+	off = align_up(off + sizeof(uint2) * (size_t)n_tiles, A);
+	const size_t seg_bytes = align_up(sizeof(double) * (size_t)n_seg, A);
+	const size_t off_sx = off, off_sy = off + seg_bytes, off_ex = off + 2 * seg_bytes,
+	             off_ey = off + 3 * seg_bytes;
+	off += 4 * seg_bytes;
+	b->input_bytes = off;
+	const size_t off_out = off;
+	off = align_up(off + (size_t)n_pix, A);
+	b->arena_bytes = off ? off : A;
+
+	(void)hipSetDevice(ctx->device);
+	hipError_t e = hipMalloc(&b->d_arena, b->arena_bytes);
+	if (e != hipSuccess) {
+		ctx->err = std::string("vgsdf_batch_upload: hipMalloc: ") + hipGetErrorString(e);
+		delete b;
+		return VGSDF_E_OOM;
+	}
+	if (b->input_bytes) {
+		e = hipHostMalloc(&b->h_stage, b->input_bytes, hipHostMallocDefault);
+		if (e != hipSuccess) {
+			ctx->err = std::string("vgsdf_batch_upload: hipHostMalloc: ") + hipGetErrorString(e);
+			vgsdf_batch_free(ctx, b);
+			return VGSDF_E_OOM;
+		}
+	}
+	uint8_t *hs = (uint8_t *)b->h_stage, *da = (uint8_t *)b->d_arena;
+	b->d_glyphs = (vgsdf::GlyphDesc *)(da + off_desc);
+	b->d_tiles = (uint2 *)(da + off_tiles);
+	b->d_sx = (double *)(da + off_sx);
+	b->d_sy = (double *)(da + off_sy);
+	b->d_ex = (double *)(da + off_ex);
+	b->d_ey = (double *)(da + off_ey);
+	b->d_out = da + off_out;
+
+	if (n) {
+		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
+		uint2 *ht = (uint2 *)(hs + off_tiles);
+		uint64_t ti = 0;
+		for (uint32_t g = 0; g < n; g++) {
+			hd[g].seg_off = in->seg_off[g];
+			hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
+			hd[g].x0 = in->x0[g];
+			hd[g].y0 = in->y0[g];
+			hd[g].w = in->w[g];
+			hd[g].h = in->h[g];
+			hd[g].out_off = in->out_off[g];
+			const uint32_t px = in->w[g] * in->h[g];
+			for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
+				ht[ti++] = make_uint2(g, p);
+		}
+		if (n_seg) {
+			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
+			std::memcpy(hs + off_sy, in->seg_sy, sizeof(double) * n_seg);
+			std::memcpy(hs + off_ex, in->seg_ex, sizeof(double) * n_seg);
+			std::memcpy(hs + off_ey, in->seg_ey, sizeof(double) * n_seg);
+		}
+		e = hipMemcpyAsync(b->d_arena, b->h_stage, b->input_bytes, hipMemcpyHostToDevice, ctx->stream);
+		if (e != hipSuccess) {
+			ctx->err = std::string("vgsdf_batch_upload: H2D: ") + hipGetErrorString(e);
+			vgsdf_batch_free(ctx, b);
+			return VGSDF_E_HIP;
+		}
+	}
+	*out = b;
+	return VGSDF_OK;
+}
+
+int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!b) {
+		ctx->err = "vgsdf_batch_launch: NULL batch";
+		return VGSDF_E_ARG;
+	}
+	(void)hipSetDevice(ctx->device);
+	int e = vgsdf_launch_tiles(ctx->variant, b->d_glyphs, b->d_tiles, (uint32_t)b->stats.n_tiles, b->d_sx,
+	                           b->d_sy, b->d_ex, b->d_ey, b->d_out, ctx->stream);
+	if (e != 0) {
+		ctx->err = std::string("vgsdf_batch_launch: ") + hipGetErrorString((hipError_t)e);
+		return VGSDF_E_HIP;
+	}
+	return VGSDF_OK;
+}
+
+int vgsdf_batch_download(vgsdf_ctx *ctx, vgsdf_dbatch *b, uint8_t *out_bitmaps)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!b || (!out_bitmaps && b->out_bytes)) {
+		ctx->err = "vgsdf_batch_download: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	(void)hipSetDevice(ctx->device);
+	if (b->out_bytes)
+		HIP_TRY(ctx, hipMemcpyAsync(out_bitmaps, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return VGSDF_OK;
+}
+
+int vgsdf_batch_stats(const vgsdf_dbatch *b, vgsdf_stats *out)
+{
+	if (!b || !out)
+		return VGSDF_E_ARG;
+	*out = b->stats;
+	return VGSDF_OK;
+}
+
+void *vgsdf_batch_device_output(const vgsdf_dbatch *b) { return b ? b->d_out : nullptr; }
+
+int vgsdf_batch_time(vgsdf_ctx *ctx, vgsdf_dbatch *b, int iters, float *total_ms)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!b || !total_ms || iters < 1) {
+		ctx->err = "vgsdf_batch_time: bad argument";
+		return VGSDF_E_ARG;
+	}
+	(void)hipSetDevice(ctx->device);
+	HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+	for (int i = 0; i < iters; i++) {
+		int rc = vgsdf_batch_launch(ctx, b);
+		if (rc != VGSDF_OK)
+			return rc;
+	}
+	HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+	HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+	HIP_TRY(ctx, hipEventElapsedTime(total_ms, ctx->ev0, ctx->ev1));
+	return VGSDF_OK;
+}
+
+int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitmaps)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	vgsdf_dbatch *b = nullptr;
+	int rc = vgsdf_batch_upload(ctx, in, &b);
+	if (rc != VGSDF_OK)
+		return rc;
+	rc = vgsdf_batch_launch(ctx, b);
+	if (rc == VGSDF_OK)
+		rc = vgsdf_batch_download(ctx, b, out_bitmaps);
+	vgsdf_batch_free(ctx, b);
+	return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,211 @@
+"""ctypes binding of include/vgsdf.h (the device boundary)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from .build import lib_path
+
+
+class VgsdfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vgsdf error {code}: {msg}")
+        self.code = code
+
+
+class _CBatch(C.Structure):
+    _fields_ = [("n_glyphs", C.c_uint32), ("seg_off", C.c_void_p), ("seg_sx", C.c_void_p),
+                ("seg_sy", C.c_void_p), ("seg_ex", C.c_void_p), ("seg_ey", C.c_void_p),
+                ("x0", C.c_void_p), ("y0", C.c_void_p), ("w", C.c_void_p), ("h", C.c_void_p),
+                ("out_off", C.c_void_p)]
+
+
+class _CStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_glyphs", "n_segments", "n_pixels", "n_pairs", "n_tiles", "alg_bytes")]
+
+
+VGSDF_SYMBOLS = [
+    "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
+    "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
+    "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvgsdf.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not p.exists():
+            raise FileNotFoundError(f"{p} missing: run __graft_entry__.build() (hipcc) first; "
+                                    "there is no CPU fallback")
+        L = C.CDLL(str(p))
+        vp = C.c_void_p
+        L.vgsdf_device_count.restype = C.c_int
+        L.vgsdf_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.vgsdf_destroy.argtypes = [vp]
+        L.vgsdf_destroy.restype = None
+        L.vgsdf_last_error.argtypes = [vp]
+        L.vgsdf_last_error.restype = C.c_char_p
+        L.vgsdf_render_batch.argtypes = [vp, C.POINTER(_CBatch), vp]
+        L.vgsdf_batch_upload.argtypes = [vp, C.POINTER(_CBatch), C.POINTER(vp)]
+        L.vgsdf_batch_launch.argtypes = [vp, vp]
+        L.vgsdf_batch_download.argtypes = [vp, vp, vp]
+        L.vgsdf_batch_free.argtypes = [vp, vp]
+        L.vgsdf_sync.argtypes = [vp]
+        L.vgsdf_batch_stats.argtypes = [vp, C.POINTER(_CStats)]
+        L.vgsdf_batch_time.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float)]
+        L.vgsdf_set_variant.argtypes = [vp, C.c_int]
+        L.vgsdf_batch_device_output.argtypes = [vp]
+        L.vgsdf_batch_device_output.restype = vp
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return load_library().vgsdf_device_count()
+
+
+@dataclass
+class Batch:
+    """Host SoA batch (vgsdf_batch).  Arrays are kept alive by this object."""
+    seg_off: np.ndarray  # u32 [n+1]
+    seg_sx: np.ndarray   # f64 [S]
+    seg_sy: np.ndarray
+    seg_ex: np.ndarray
+    seg_ey: np.ndarray
+    x0: np.ndarray       # i32 [n]
+    y0: np.ndarray
+    w: np.ndarray        # u32 [n]
+    h: np.ndarray
+    out_off: np.ndarray  # u64 [n+1]
+
+    @property
+    def n_glyphs(self) -> int:
+        return len(self.w)
+
+    @property
+    def out_bytes(self) -> int:
+        return int(self.out_off[-1]) if len(self.out_off) else 0
+
+    def c_struct(self) -> _CBatch:
+        p = lambda a: a.ctypes.data  # noqa: E731
+        return _CBatch(self.n_glyphs, p(self.seg_off), p(self.seg_sx), p(self.seg_sy), p(self.seg_ex),
+                       p(self.seg_ey), p(self.x0), p(self.y0), p(self.w), p(self.h), p(self.out_off))
+
+    def bitmap(self, out: np.ndarray, g: int) -> np.ndarray:
+        a, b = int(self.out_off[g]), int(self.out_off[g + 1])
+        return out[a:b].reshape(int(self.h[g]), int(self.w[g]))
+
+
+def make_batch(glyphs) -> Batch:
+    """glyphs: iterable of (segs[n,4] f64 (sx,sy,ex,ey), x0, y0, w, h)."""
+    glyphs = list(glyphs)
+    n = len(glyphs)
+    seg_off = np.zeros(n + 1, dtype=np.uint32)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    x0 = np.zeros(n, dtype=np.int32)
+    y0 = np.zeros(n, dtype=np.int32)
+    w = np.zeros(n, dtype=np.uint32)
+    h = np.zeros(n, dtype=np.uint32)
+    parts = []
+    for i, (segs, gx0, gy0, gw, gh) in enumerate(glyphs):
+        segs = np.ascontiguousarray(segs, dtype=np.float64).reshape(-1, 4)
+        parts.append(segs)
+        seg_off[i + 1] = seg_off[i] + len(segs)
+        out_off[i + 1] = out_off[i] + np.uint64(int(gw) * int(gh))
+        x0[i], y0[i], w[i], h[i] = gx0, gy0, gw, gh
+    allseg = np.concatenate(parts, axis=0) if parts else np.zeros((0, 4))
+    col = lambda k: np.ascontiguousarray(allseg[:, k])  # noqa: E731
+    return Batch(seg_off, col(0), col(1), col(2), col(3), x0, y0, w, h, out_off)
+
+
+class DeviceBatch:
+    """A batch resident in HBM (vgsdf_dbatch)."""
+
+    def __init__(self, ctx: "SdfContext", handle, out_bytes: int):
+        self.ctx, self._h, self.out_bytes = ctx, handle, out_bytes
+
+    def launch(self):
+        self.ctx._check(load_library().vgsdf_batch_launch(self.ctx._h, self._h))
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.out_bytes, dtype=np.uint8)
+        self.ctx._check(load_library().vgsdf_batch_download(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+    def time(self, iters: int) -> float:
+        """total milliseconds for `iters` launches (HIP events on the context stream)."""
+        ms = C.c_float(0)
+        self.ctx._check(load_library().vgsdf_batch_time(self.ctx._h, self._h, iters, C.byref(ms)))
+        return float(ms.value)
+
+    def stats(self) -> dict:
+        s = _CStats()
+        load_library().vgsdf_batch_stats(self._h, C.byref(s))
+        return {k: int(getattr(s, k)) for k, _ in _CStats._fields_}
+
+    def device_output_ptr(self) -> int:
+        return int(load_library().vgsdf_batch_device_output(self._h) or 0)
+
+    def free(self):
+        if self._h:
+            load_library().vgsdf_batch_free(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+
+class SdfContext:
+    """vgsdf_ctx: one per (thread, GPU)."""
+
+    def __init__(self, device: int = 0):
+        L = load_library()
+        h = C.c_void_p()
+        rc = L.vgsdf_create(device, C.byref(h))
+        if rc != 0:
+            raise VgsdfError(rc, (L.vgsdf_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise VgsdfError(rc, (load_library().vgsdf_last_error(self._h) or b"").decode())
+
+    def set_variant(self, v: int):
+        self._check(load_library().vgsdf_set_variant(self._h, v))
+
+    def render_batch(self, batch: Batch) -> np.ndarray:
+        out = np.empty(batch.out_bytes, dtype=np.uint8)
+        cb = batch.c_struct()
+        self._check(load_library().vgsdf_render_batch(self._h, C.byref(cb), out.ctypes.data))
+        return out
+
+    def upload(self, batch: Batch) -> DeviceBatch:
+        cb = batch.c_struct()
+        h = C.c_void_p()
+        self._check(load_library().vgsdf_batch_upload(self._h, C.byref(cb), C.byref(h)))
+        self.sync()
+        return DeviceBatch(self, h, batch.out_bytes)
+
+    def sync(self):
+        self._check(load_library().vgsdf_sync(self._h))
+
+    def close(self):
+        if self._h:
+            load_library().vgsdf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
