@@ -1,0 +1,93 @@
+/*
+ * vgfont.h — flat C view of the C++ host façade in libvgsdf.so (namespace vg):
+ * FontManager / GlyphBlock / Renderer with the reference's names and semantics, driving
+ * the GPU raster of vgsdf.h.  Replaces, for the render path only:
+ *   FontManager::{new,add_font_with_name,render_glyphs}  /root/reference/src/font/manager.rs:28,66,81
+ *   GlyphBlock::render                                   src/font/glyph_block.rs:69
+ *   Renderer::{new,new_precise,new_dummy,render_glyph}   src/render/renderer.rs:25-43,103
+ * This header exists so tests/bench (Python ctypes) and non-C++ callers can reach the
+ * façade; C++ callers include csrc/host/font_manager.hpp directly.
+ *
+ * Return convention: >= 0 success, < 0 failure with the message in vg_last_error()
+ * (thread-local).  Renderer mode VG_MODE_HIP has no CPU fallback.
+ */
+#ifndef VGFONT_H
+#define VGFONT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "vgsdf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vg_manager vg_manager;
+typedef struct vg_renderer vg_renderer;
+typedef struct vg_glyph_batch vg_glyph_batch;
+
+enum { VG_MODE_HIP = 0, VG_MODE_DUMMY = 1 }; /* renderer.rs:14-17 RendererMode {Precise,Dummy} */
+
+/* PbfGlyph (src/protobuf/glyph.rs:10-41) without the pixels */
+typedef struct {
+	uint32_t id;
+	int32_t has_bitmap;
+	uint32_t width, height;
+	int32_t left, top;
+	uint32_t advance;
+	uint32_t bitmap_len;
+} vg_pbf_glyph;
+
+/* phases of the last vg_manager_render_glyphs call */
+typedef struct {
+	double tessellate_s, device_s, encode_s, write_s, total_s;
+	uint64_t blocks, glyphs, rasters, pixels, segments, pbf_bytes;
+} vg_timings;
+
+/* Writer sink (src/writer/mod.rs:10-19): is_dir=1 for write_directory. Return 0, or
+ * non-zero to abort the render (first error aborts, manager.rs:117-121). */
+typedef int (*vg_write_cb)(void *user, const char *path, const uint8_t *data, size_t len, int is_dir);
+
+const char *vg_last_error(void);
+
+vg_renderer *vg_renderer_new(int mode, int device_ordinal);
+void vg_renderer_free(vg_renderer *r);
+
+vg_manager *vg_manager_new(int parallel);
+void vg_manager_free(vg_manager *m);
+void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch);
+int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
+int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
+int vg_manager_add_path(vg_manager *m, const char *path); /* always fails: out of scope, see header */
+/* name_to_id (manager.rs:141-147); writes a NUL-terminated id, returns its length */
+int vg_name_to_id(const char *name, char *out, size_t cap);
+/* number of code points (<= 0xFFFF) the font id maps after first-provider-wins merging */
+int vg_manager_block_counts(const vg_manager *m, const char *font_id, uint32_t counts[256]);
+
+int vg_manager_render_glyphs(vg_manager *m, vg_renderer *r, vg_write_cb cb, void *user);
+int vg_manager_timings(const vg_manager *m, vg_timings *out);
+/* GlyphBlock::render for one block of one font -> PBF bytes; returns needed size */
+long vg_manager_render_block(vg_manager *m, vg_renderer *r, const char *font_id, uint32_t start, uint8_t *out,
+                             size_t cap);
+
+/* Renderer::render_glyph(face, index): 1 = Some, 0 = None.  file_index selects the file
+ * inside the font id (wrapper.files order). */
+int vg_render_glyph(vg_renderer *r, const vg_manager *m, const char *font_id, int file_index, uint32_t index,
+                    vg_pbf_glyph *out, uint8_t *bitmap, size_t cap);
+
+/* Host stage only (cmap -> outline -> flatten -> scale/shift -> bbox) for every glyph of a
+ * font id: the SoA batch to hand to vgsdf_batch_upload.  Pointers in *view stay valid
+ * until vg_glyph_batch_free.  ids[i] = code point of rasterised glyph i. */
+vg_glyph_batch *vg_manager_build_batch(const vg_manager *m, const char *font_id);
+int vg_glyph_batch_view(const vg_glyph_batch *b, vgsdf_batch *view, const uint32_t **ids, uint32_t *n_jobs);
+void vg_glyph_batch_free(vg_glyph_batch *b);
+
+/* Hand-encoder of the glyphs PBF (src/protobuf/glyphs.rs:66-70) for already rendered
+ * glyphs; bitmaps[i] may be NULL when !has_bitmap. Returns needed size. */
+long vg_pbf_encode(const char *name, const char *range, const vg_pbf_glyph *glyphs, const uint8_t *const *bitmaps,
+                   int n, uint8_t *out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

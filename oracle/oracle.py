@@ -75,6 +75,8 @@ def lib():
         L.vgo_render_all.restype = C.c_double
         L.vgo_render_all.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(C.c_uint64)]
+        L.vgo_sdf_render_batch.restype = C.c_double
+        L.vgo_sdf_render_batch.argtypes = [C.c_uint32] + [vp] * 10 + [C.c_int, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -230,3 +232,16 @@ def render_all(fonts, name: str, mode: int = PRECISE, threads: int = 1, only_blo
 
 def default_threads() -> int:
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def sdf_render_batch(batch, mode: int = PRECISE, threads: int = 0):
+    """Raster-only over a whole SoA batch (object with the vgsdf_batch arrays as numpy
+    attributes: seg_off, seg_sx, seg_sy, seg_ex, seg_ey, x0, y0, w, h, out_off).
+    -> (u8 output buffer, wall seconds)"""
+    n = len(batch.w)
+    out = np.zeros(int(batch.out_off[-1]) if n else 0, dtype=np.uint8)
+    p = lambda a: a.ctypes.data  # noqa: E731
+    secs = lib().vgo_sdf_render_batch(n, p(batch.seg_off), p(batch.seg_sx), p(batch.seg_sy), p(batch.seg_ex),
+                                      p(batch.seg_ey), p(batch.x0), p(batch.y0), p(batch.w), p(batch.h),
+                                      p(batch.out_off), mode, threads or default_threads(), p(out))
+    return out, secs

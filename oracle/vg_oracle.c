@@ -1489,3 +1489,74 @@ double vgo_render_all(const vgo_font *const *fonts, int n_fonts, const char *nam
 	}
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------------------
+ * batch raster (test + baseline helper; same per-glyph routine as above)
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	uint32_t n;
+	const uint32_t *seg_off;
+	const double *sx, *sy, *ex, *ey;
+	const int32_t *x0, *y0;
+	const uint32_t *w, *h;
+	const uint64_t *out_off;
+	int mode;
+	uint8_t *out;
+	uint32_t next;
+	pthread_mutex_t mu;
+} batch_job;
+
+static void *batch_worker(void *arg)
+{
+	batch_job *j = (batch_job *)arg;
+	double *segs = NULL;
+	size_t cap = 0;
+	for (;;) {
+		pthread_mutex_lock(&j->mu);
+		uint32_t g0 = j->next;
+		j->next += 4;
+		pthread_mutex_unlock(&j->mu);
+		if (g0 >= j->n)
+			break;
+		for (uint32_t g = g0; g < g0 + 4 && g < j->n; g++) {
+			uint32_t a = j->seg_off[g], n = j->seg_off[g + 1] - a;
+			if (n > cap) {
+				cap = n;
+				segs = (double *)realloc(segs, sizeof(double) * 4 * cap);
+			}
+			for (uint32_t i = 0; i < n; i++) {
+				segs[4 * i] = j->sx[a + i];
+				segs[4 * i + 1] = j->sy[a + i];
+				segs[4 * i + 2] = j->ex[a + i];
+				segs[4 * i + 3] = j->ey[a + i];
+			}
+			vgo_sdf_render(segs, (int)n, j->x0[g], j->y0[g], (int)j->w[g], (int)j->h[g], j->mode,
+			               j->out + j->out_off[g]);
+		}
+	}
+	free(segs);
+	return NULL;
+}
+
+double vgo_sdf_render_batch(uint32_t n_glyphs, const uint32_t *seg_off, const double *sx,
+                            const double *sy, const double *ex, const double *ey,
+                            const int32_t *x0, const int32_t *y0, const uint32_t *w,
+                            const uint32_t *h, const uint64_t *out_off, int mode, int threads,
+                            uint8_t *out)
+{
+	batch_job j = {n_glyphs, seg_off, sx, sy, ex, ey, x0, y0, w, h, out_off, mode, out, 0,
+	               PTHREAD_MUTEX_INITIALIZER};
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	if (threads < 1)
+		threads = 1;
+	if (threads > 256)
+		threads = 256;
+	pthread_t th[256];
+	for (int i = 0; i < threads; i++)
+		pthread_create(&th[i], NULL, batch_worker, &j);
+	for (int i = 0; i < threads; i++)
+		pthread_join(th[i], NULL);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -109,6 +109,15 @@ size_t vgo_render_block(const vgo_font *const *fonts, int n_fonts, const char *n
 double vgo_render_all(const vgo_font *const *fonts, int n_fonts, const char *name, int mode,
                       int threads, int only_block, uint64_t counters[6]);
 
+/* renderer_precise over a whole SoA batch (same layout as include/vgsdf.h), glyphs
+ * distributed dynamically over `threads` workers.  Raster only: this is the CPU figure the
+ * GPU kernel is compared with on identical, already tessellated input. returns wall seconds. */
+double vgo_sdf_render_batch(uint32_t n_glyphs, const uint32_t *seg_off, const double *sx,
+                            const double *sy, const double *ex, const double *ey,
+                            const int32_t *x0, const int32_t *y0, const uint32_t *w,
+                            const uint32_t *h, const uint64_t *out_off, int mode, int threads,
+                            uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

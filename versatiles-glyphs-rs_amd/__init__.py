@@ -11,3 +11,6 @@ from .build import build, lib_path  # noqa: F401
 from .device import (  # noqa: F401
     Batch, DeviceBatch, SdfContext, VgsdfError, device_count, make_batch, load_library,
 )
+from .host import (  # noqa: F401
+    DummyWriter, FontManager, GlyphBatchHost, PbfGlyph, Renderer, name_to_id, pbf_encode,
+)

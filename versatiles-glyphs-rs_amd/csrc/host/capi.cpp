@@ -1,0 +1,230 @@
+// capi.cpp — flat C view (include/vgfont.h) of the C++ host façade.
+#include <cstring>
+#include <stdexcept>
+
+#include "../../../include/vgfont.h"
+#include "font_manager.hpp"
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::string &m)
+{
+	g_err = m;
+	return -1;
+}
+} // namespace
+
+struct vg_renderer {
+	std::shared_ptr<vg::Renderer> r;
+};
+struct vg_manager {
+	vg::FontManager m;
+	explicit vg_manager(bool p) : m(p) {}
+};
+struct vg_glyph_batch {
+	vg::GlyphBatch b;
+	std::vector<uint32_t> ids;
+};
+
+namespace {
+struct CallbackWriter final : vg::Writer {
+	vg_write_cb cb;
+	void *user;
+	CallbackWriter(vg_write_cb c, void *u) : cb(c), user(u) {}
+	void write_directory(const std::string &p) override
+	{
+		if (cb && cb(user, p.c_str(), nullptr, 0, 1) != 0)
+			throw std::runtime_error("writer callback failed for " + p);
+	}
+	void write_file(const std::string &p, const std::vector<uint8_t> &d) override
+	{
+		if (cb && cb(user, p.c_str(), d.data(), d.size(), 0) != 0)
+			throw std::runtime_error("writer callback failed for " + p);
+	}
+};
+} // namespace
+
+extern "C" {
+
+const char *vg_last_error(void) { return g_err.c_str(); }
+
+vg_renderer *vg_renderer_new(int mode, int device)
+{
+	std::string err;
+	auto r = mode == VG_MODE_DUMMY ? vg::Renderer::new_dummy() : vg::Renderer::new_precise(device, &err);
+	if (!r) {
+		g_err = err;
+		return nullptr;
+	}
+	return new vg_renderer{std::move(r)};
+}
+void vg_renderer_free(vg_renderer *r) { delete r; }
+
+vg_manager *vg_manager_new(int parallel) { return new vg_manager(parallel != 0); }
+void vg_manager_free(vg_manager *m) { delete m; }
+void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch)
+{
+	m->m.set_threads(threads);
+	if (blocks_per_batch)
+		m->m.set_batch_blocks(blocks_per_batch);
+}
+
+int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n)
+{
+	std::vector<std::string> ps(paths, paths + n);
+	std::string err;
+	return m->m.add_font_with_name(name, ps, &err) ? 0 : fail(err);
+}
+int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len)
+{
+	std::string err;
+	return m->m.add_font_data(name, std::vector<uint8_t>(data, data + len), &err) ? 0 : fail(err);
+}
+int vg_manager_add_path(vg_manager *m, const char *path)
+{
+	std::string err;
+	return m->m.add_path(path, &err) ? 0 : fail(err);
+}
+int vg_name_to_id(const char *name, char *out, size_t cap)
+{
+	const std::string id = vg::name_to_id(name);
+	if (out && cap) {
+		const size_t n = std::min(cap - 1, id.size());
+		std::memcpy(out, id.data(), n);
+		out[n] = 0;
+	}
+	return (int)id.size();
+}
+int vg_manager_block_counts(const vg_manager *m, const char *font_id, uint32_t counts[256])
+{
+	auto it = m->m.fonts().find(font_id);
+	if (it == m->m.fonts().end())
+		return fail(std::string("unknown font id ") + font_id);
+	const auto blocks = it->second.get_blocks();
+	for (size_t i = 0; i < 256; i++)
+		counts[i] = (uint32_t)blocks[i].len();
+	return 0;
+}
+
+int vg_manager_render_glyphs(vg_manager *m, vg_renderer *r, vg_write_cb cb, void *user)
+{
+	try {
+		CallbackWriter w(cb, user);
+		m->m.render_glyphs(w, *r->r);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+int vg_manager_timings(const vg_manager *m, vg_timings *out)
+{
+	const vg::RenderTimings &t = m->m.last_timings();
+	*out = vg_timings{t.tessellate_s, t.device_s, t.encode_s, t.write_s, t.total_s, t.blocks,
+	                  t.glyphs,       t.rasters,  t.pixels,   t.segments, t.pbf_bytes};
+	return 0;
+}
+long vg_manager_render_block(vg_manager *m, vg_renderer *r, const char *font_id, uint32_t start, uint8_t *out,
+                             size_t cap)
+{
+	try {
+		auto it = m->m.fonts().find(font_id);
+		if (it == m->m.fonts().end())
+			return fail(std::string("unknown font id ") + font_id);
+		if (start % 256 || start > 0xFF00)
+			return fail("block start must be a multiple of 256 below 65536");
+		const auto blocks = it->second.get_blocks();
+		const std::vector<uint8_t> pbf = blocks[start / 256].render(font_id, *r->r);
+		if (out && pbf.size() <= cap)
+			std::memcpy(out, pbf.data(), pbf.size());
+		return (long)pbf.size();
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+int vg_render_glyph(vg_renderer *r, const vg_manager *m, const char *font_id, int file_index, uint32_t index,
+                    vg_pbf_glyph *out, uint8_t *bitmap, size_t cap)
+{
+	try {
+		auto it = m->m.fonts().find(font_id);
+		if (it == m->m.fonts().end())
+			return fail(std::string("unknown font id ") + font_id);
+		const auto &files = it->second.files();
+		if (file_index < 0 || (size_t)file_index >= files.size())
+			return fail("file index out of range");
+		const auto g = r->r->render_glyph(files[(size_t)file_index]->face(), index);
+		if (!g)
+			return 0;
+		out->id = g->id;
+		out->has_bitmap = g->bitmap ? 1 : 0;
+		out->width = g->width;
+		out->height = g->height;
+		out->left = g->left;
+		out->top = g->top;
+		out->advance = g->advance;
+		out->bitmap_len = g->bitmap ? (uint32_t)g->bitmap->size() : 0;
+		if (g->bitmap) {
+			if (g->bitmap->size() > cap)
+				return fail("bitmap buffer too small");
+			std::memcpy(bitmap, g->bitmap->data(), g->bitmap->size());
+		}
+		return 1;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+vg_glyph_batch *vg_manager_build_batch(const vg_manager *m, const char *font_id)
+{
+	try {
+		auto *b = new vg_glyph_batch();
+		std::string err;
+		if (!m->m.build_batch(font_id, b->b, &err)) {
+			delete b;
+			g_err = err;
+			return nullptr;
+		}
+		for (uint32_t j : b->b.raster_job)
+			b->ids.push_back(b->b.jobs[j].id);
+		return b;
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+int vg_glyph_batch_view(const vg_glyph_batch *b, vgsdf_batch *view, const uint32_t **ids, uint32_t *n_jobs)
+{
+	*view = b->b.view();
+	if (ids)
+		*ids = b->ids.data();
+	if (n_jobs)
+		*n_jobs = (uint32_t)b->b.jobs.size();
+	return 0;
+}
+void vg_glyph_batch_free(vg_glyph_batch *b) { delete b; }
+
+long vg_pbf_encode(const char *name, const char *range, const vg_pbf_glyph *glyphs, const uint8_t *const *bitmaps,
+                   int n, uint8_t *out, size_t cap)
+{
+	std::vector<vg::PbfGlyphRef> refs((size_t)n);
+	static const uint8_t kEmpty = 0;
+	for (int i = 0; i < n; i++) {
+		vg::PbfGlyphRef &r = refs[(size_t)i];
+		r.id = glyphs[i].id;
+		if (glyphs[i].has_bitmap) {
+			r.bitmap = bitmaps && bitmaps[i] ? bitmaps[i] : &kEmpty;
+			r.bitmap_len = glyphs[i].bitmap_len;
+		}
+		r.width = glyphs[i].width;
+		r.height = glyphs[i].height;
+		r.left = glyphs[i].left;
+		r.top = glyphs[i].top;
+		r.advance = glyphs[i].advance;
+	}
+	const std::vector<uint8_t> pbf = vg::PbfGlyphs::encode(name, range, std::move(refs));
+	if (out && pbf.size() <= cap)
+		std::memcpy(out, pbf.data(), pbf.size());
+	return (long)pbf.size();
+}
+
+} // extern "C"

@@ -1,0 +1,125 @@
+// font_manager.hpp — host mirror of the reference's orchestration layer for the render
+// path, with the rayon block loop replaced by a GPU batch dispatcher.
+//
+//   FontFileEntry                       /root/reference/src/font/file_entry.rs:16-56
+//   FontWrapper::{add_file,get_blocks}  src/font/wrapper.rs:21-76
+//   GlyphBlock::{set_glyph_font,render,filename}   src/font/glyph_block.rs:10-90
+//   FontManager::{new,add_font_with_name,render_glyphs}  src/font/manager.rs:18-125
+//   name_to_id                          manager.rs:141-147
+//   WriterTrait                         src/writer/mod.rs:10-19
+//
+// Out of scope: family-name parsing (add_path), index/families JSON, tar.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "renderer.hpp"
+
+namespace vg {
+
+constexpr uint32_t GLYPH_BLOCK_SIZE = 256; // glyph_block.rs:7
+
+// Sink for rendered files (writer/mod.rs:10-19).  write_file may be called from the
+// dispatcher thread only (the reference serialises writers behind a Mutex, manager.rs:102).
+struct Writer {
+	virtual ~Writer() = default;
+	virtual void write_directory(const std::string &path) = 0;
+	virtual void write_file(const std::string &path, const std::vector<uint8_t> &data) = 0;
+};
+
+// file_entry.rs: owns the bytes, the parsed face and the cmap coverage
+class FontFileEntry {
+public:
+	static std::unique_ptr<FontFileEntry> create(std::vector<uint8_t> data, std::string *err);
+	const Face &face() const { return face_; }
+	const std::vector<uint32_t> &codepoints() const { return codepoints_; } // metadata.rs:105-119
+
+private:
+	std::vector<uint8_t> data_;
+	Face face_;
+	std::vector<uint32_t> codepoints_;
+};
+
+// glyph_block.rs:10-16 — which file renders each of the 256 code points of a range
+struct GlyphBlock {
+	uint32_t start_index = 0;
+	std::array<const FontFileEntry *, GLYPH_BLOCK_SIZE> glyphs{}; // nullptr = unmapped
+	uint32_t count = 0;
+
+	// glyph_block.rs:34-36: first provider wins
+	void set_glyph_font(uint8_t char_index, const FontFileEntry *font)
+	{
+		if (!glyphs[char_index]) {
+			glyphs[char_index] = font;
+			count++;
+		}
+	}
+	size_t len() const { return count; }
+	bool is_empty() const { return count == 0; }
+	std::string range() const; // glyph_block.rs:53-59
+	std::string filename() const { return range() + ".pbf"; } // :85-87
+
+	// Host half of GlyphBlock::render (glyph_block.rs:72-77), glyphs in ascending id.
+	void prepare(TessScratch &scratch, GlyphBatch &batch) const;
+	// glyph_block.rs:69-80 complete (one block through the renderer)
+	std::vector<uint8_t> render(const std::string &font_name, const Renderer &renderer) const;
+};
+
+// wrapper.rs:15-19
+class FontWrapper {
+public:
+	void add_file(std::unique_ptr<FontFileEntry> f) { files_.push_back(std::move(f)); }
+	bool add_paths(const std::vector<std::string> &paths, std::string *err); // wrapper.rs:31-39
+	const std::vector<std::unique_ptr<FontFileEntry>> &files() const { return files_; }
+	std::vector<GlyphBlock> get_blocks() const; // wrapper.rs:53-76: always 256 blocks
+
+private:
+	std::vector<std::unique_ptr<FontFileEntry>> files_;
+};
+
+struct RenderTimings {
+	double tessellate_s = 0, device_s = 0, encode_s = 0, write_s = 0, total_s = 0;
+	uint64_t blocks = 0, glyphs = 0, rasters = 0, pixels = 0, segments = 0, pbf_bytes = 0;
+};
+
+class FontManager {
+public:
+	explicit FontManager(bool parallel) : parallel_(parallel) {} // manager.rs:28-33
+
+	// manager.rs:66-75
+	bool add_font_with_name(const std::string &name, const std::vector<std::string> &sources, std::string *err);
+	bool add_font_data(const std::string &name, std::vector<uint8_t> data, std::string *err);
+	// manager.rs:39-53 needs family-name parsing (parse_font_name.rs), which is out of scope
+	bool add_path(const std::string &path, std::string *err);
+
+	// manager.rs:81-125.  Host threads tessellate blocks into SoA batches, the GPU renders
+	// them, blocks are PBF-encoded and handed to the writer in task order.  Throws
+	// std::runtime_error on failure (first error aborts, like try_for_each).
+	void render_glyphs(Writer &writer, const Renderer &renderer);
+
+	// Host stage only: every rasterised glyph of one font, blocks in ascending order (the
+	// batch a bench/test keeps resident in HBM).
+	bool build_batch(const std::string &font_id, GlyphBatch &out, std::string *err) const;
+
+	const std::map<std::string, FontWrapper> &fonts() const { return fonts_; }
+	const RenderTimings &last_timings() const { return timings_; }
+	void set_threads(unsigned n) { threads_ = n; }
+	void set_batch_blocks(unsigned n) { batch_blocks_ = n ? n : 1; }
+
+private:
+	unsigned worker_count() const;
+	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
+	bool parallel_;
+	unsigned threads_ = 0;       // 0 = hardware_concurrency
+	unsigned batch_blocks_ = 64; // blocks per GPU submission
+	RenderTimings timings_;
+};
+
+std::string name_to_id(const std::string &name); // manager.rs:141-147
+
+} // namespace vg

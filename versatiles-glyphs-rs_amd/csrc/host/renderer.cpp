@@ -1,0 +1,227 @@
+#include "renderer.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace vg {
+
+namespace {
+
+// Rust `as i32` / `as u32` on f64: truncate, saturate, NaN -> 0
+inline int32_t to_i32(double v)
+{
+	if (std::isnan(v))
+		return 0;
+	if (v >= 2147483647.0)
+		return INT32_MAX;
+	if (v <= -2147483648.0)
+		return INT32_MIN;
+	return (int32_t)v;
+}
+inline uint32_t to_u32(double v)
+{
+	if (std::isnan(v) || v <= 0.0)
+		return 0;
+	if (v >= 4294967295.0)
+		return UINT32_MAX;
+	return (uint32_t)v;
+}
+
+} // namespace
+
+void GlyphBatch::clear()
+{
+	jobs.clear();
+	raster_job.clear();
+	seg_off.assign(1, 0);
+	sx.clear();
+	sy.clear();
+	ex.clear();
+	ey.clear();
+	x0.clear();
+	y0.clear();
+	w.clear();
+	h.clear();
+	out_off.assign(1, 0);
+}
+
+vgsdf_batch GlyphBatch::view() const
+{
+	vgsdf_batch b;
+	b.n_glyphs = (uint32_t)w.size();
+	b.seg_off = seg_off.data();
+	b.seg_sx = sx.data();
+	b.seg_sy = sy.data();
+	b.seg_ex = ex.data();
+	b.seg_ey = ey.data();
+	b.x0 = x0.data();
+	b.y0 = y0.data();
+	b.w = w.data();
+	b.h = h.data();
+	b.out_off = out_off.data();
+	return b;
+}
+
+void GlyphBatch::append(const GlyphBatch &o)
+{
+	const uint32_t job_base = (uint32_t)jobs.size();
+	const uint32_t seg_base = seg_off.back();
+	const uint64_t out_base = out_off.back();
+	jobs.insert(jobs.end(), o.jobs.begin(), o.jobs.end());
+	for (uint32_t j : o.raster_job)
+		raster_job.push_back(job_base + j);
+	for (size_t i = 1; i < o.seg_off.size(); i++)
+		seg_off.push_back(seg_base + o.seg_off[i]);
+	sx.insert(sx.end(), o.sx.begin(), o.sx.end());
+	sy.insert(sy.end(), o.sy.begin(), o.sy.end());
+	ex.insert(ex.end(), o.ex.begin(), o.ex.end());
+	ey.insert(ey.end(), o.ey.begin(), o.ey.end());
+	x0.insert(x0.end(), o.x0.begin(), o.x0.end());
+	y0.insert(y0.end(), o.y0.begin(), o.y0.end());
+	w.insert(w.end(), o.w.begin(), o.w.end());
+	h.insert(h.end(), o.h.begin(), o.h.end());
+	for (size_t i = 1; i < o.out_off.size(); i++)
+		out_off.push_back(out_base + o.out_off[i]);
+}
+
+std::shared_ptr<Renderer> Renderer::create(bool dummy, int device, std::string *err)
+{
+	return dummy ? new_dummy() : new_precise(device, err);
+}
+
+std::shared_ptr<Renderer> Renderer::new_dummy()
+{
+	std::shared_ptr<Renderer> r(new Renderer());
+	r->mode_ = Mode::Dummy;
+	return r;
+}
+
+std::shared_ptr<Renderer> Renderer::new_precise(int device, std::string *err)
+{
+	std::shared_ptr<Renderer> r(new Renderer());
+	r->mode_ = Mode::Hip;
+	r->device_ = device;
+	const int rc = vgsdf_create(device, &r->ctx_);
+	if (rc != VGSDF_OK) {
+		if (err)
+			*err = vgsdf_last_error(nullptr);
+		return nullptr; // no CPU fallback: the caller must fail
+	}
+	return r;
+}
+
+Renderer::~Renderer()
+{
+	if (ctx_)
+		vgsdf_destroy(ctx_);
+}
+
+bool Renderer::prepare(const Face &face, uint32_t index, TessScratch &scratch, GlyphBatch &batch)
+{
+	// renderer.rs:104 char::from_u32
+	if (index > 0x10FFFF || (index >= 0xD800 && index <= 0xDFFF))
+		return false;
+	const auto glyph_id = face.glyph_index(index); // :106
+	if (!glyph_id)
+		return false;
+	const double scale = (double)GLYPH_SIZE / (double)face.units_per_em(); // :107
+
+	scratch.builder.reset(); // :109-111
+	face.outline_glyph(*glyph_id, scratch.builder);
+	Rings &rings = scratch.builder.into_rings();
+
+	const double advance_float = (double)face.glyph_hor_advance(*glyph_id).value_or(0) * scale * 0.95; // :115
+	const uint32_t advance = to_u32(std::round(advance_float));                                          // :116
+
+	GlyphJob job;
+	job.id = index;
+	job.advance = advance;
+	if (rings.is_empty()) { // :118-120
+		batch.jobs.push_back(job);
+		return true;
+	}
+	rings.scale(scale);                                           // :122
+	const double dx = ((double)advance - advance_float) / 2.0;   // :130
+	rings.translate(Point{dx, 0.0});                              // :131
+
+	const BBox bbox = rings.get_bbox(); // prepare_glyph :64-91
+	if (bbox.is_empty()) {
+		batch.jobs.push_back(job);
+		return true;
+	}
+	job.x0 = to_i32(std::floor(bbox.min.x)) - BUFFER;
+	job.y0 = to_i32(std::floor(bbox.min.y)) - BUFFER;
+	job.x1 = to_i32(std::ceil(bbox.max.x)) + BUFFER;
+	job.y1 = to_i32(std::ceil(bbox.max.y)) + BUFFER;
+	job.width = (uint32_t)(job.x1 - job.x0);
+	job.height = (uint32_t)(job.y1 - job.y0);
+	job.has_raster = true;
+
+	// Rings::get_segments (rings.rs:75-81): consecutive point pairs, ring by ring
+	const std::vector<Point> &pts = rings.points();
+	const std::vector<uint32_t> &st = rings.starts();
+	const size_t nseg = rings.segment_count();
+	const size_t base = batch.sx.size();
+	batch.sx.resize(base + nseg);
+	batch.sy.resize(base + nseg);
+	batch.ex.resize(base + nseg);
+	batch.ey.resize(base + nseg);
+	size_t k = base;
+	for (size_t r = 0; r + 1 < st.size(); r++)
+		for (uint32_t i = st[r]; i + 1 < st[r + 1]; i++, k++) {
+			batch.sx[k] = pts[i].x;
+			batch.sy[k] = pts[i].y;
+			batch.ex[k] = pts[i + 1].x;
+			batch.ey[k] = pts[i + 1].y;
+		}
+	job.n_segments = (uint32_t)nseg;
+	batch.raster_job.push_back((uint32_t)batch.jobs.size());
+	batch.jobs.push_back(job);
+	batch.seg_off.push_back((uint32_t)(base + nseg));
+	batch.x0.push_back(job.x0);
+	batch.y0.push_back(job.y0);
+	batch.w.push_back(job.width);
+	batch.h.push_back(job.height);
+	batch.out_off.push_back(batch.out_off.back() + (uint64_t)job.width * job.height);
+	return true;
+}
+
+void Renderer::render_batch(const GlyphBatch &batch, uint8_t *out) const
+{
+	if (batch.n_raster() == 0)
+		return;
+	if (mode_ == Mode::Dummy) { // renderer_dummy.rs:3-5
+		std::memset(out, 0, (size_t)batch.out_bytes());
+		return;
+	}
+	std::lock_guard<std::mutex> lock(mu_);
+	const vgsdf_batch v = batch.view();
+	if (vgsdf_render_batch(ctx_, &v, out) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_render_batch: ") + vgsdf_last_error(ctx_));
+}
+
+std::optional<PbfGlyph> Renderer::render_glyph(const Face &face, uint32_t index) const
+{
+	TessScratch scratch;
+	GlyphBatch batch;
+	if (!prepare(face, index, scratch, batch))
+		return std::nullopt;
+	const GlyphJob &job = batch.jobs.front();
+	if (!job.has_raster)
+		return PbfGlyph::empty(job.id, job.advance);
+	std::vector<uint8_t> bitmap((size_t)batch.out_bytes());
+	render_batch(batch, bitmap.data());
+	const PbfGlyphRef r = job.to_pbf(bitmap.data());
+	PbfGlyph g;
+	g.id = r.id;
+	g.bitmap = std::move(bitmap);
+	g.width = r.width;
+	g.height = r.height;
+	g.left = r.left;
+	g.top = r.top;
+	g.advance = r.advance;
+	return g;
+}
+
+} // namespace vg

@@ -1,0 +1,119 @@
+// renderer.hpp — host mirror of the reference's Renderer (src/render/renderer.rs) with
+// the SDF raster moved to the GPU.
+//
+//   Renderer::{new,new_precise,new_dummy}   renderer.rs:25-43
+//   Renderer::prepare_glyph                 renderer.rs:64-91
+//   Renderer::render_glyph                  renderer.rs:103-149
+//   RenderResult / into_pbf_glyph           src/render/result.rs:7-29,66-76
+//   renderer_dummy                          src/render/renderer_dummy.rs:3-5
+//
+// The reference dispatches `match self.mode { Precise => renderer_precise(..), Dummy => .. }`
+// (renderer.rs:140-143).  Here Precise IS the HIP back-end: there is no CPU raster in this
+// library.  render_glyph keeps the per-glyph API; the throughput path is the batched form
+// (prepare -> GlyphBatch -> render_batch) that FontManager::render_glyphs drives.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "../../../include/vgsdf.h"
+#include "geometry.hpp"
+#include "pbf.hpp"
+#include "ring_builder.hpp"
+#include "ttf_face.hpp"
+
+namespace vg {
+
+constexpr int32_t GLYPH_SIZE = 24; // src/render/mod.rs:52
+constexpr int32_t BUFFER = 3;      // mod.rs:58
+
+// RenderResult (result.rs:7-29) + what into_pbf_glyph needs, minus the pixels
+struct GlyphJob {
+	uint32_t id = 0;
+	uint32_t advance = 0;
+	bool has_raster = false; // false => PbfGlyph::empty(id, advance)
+	int32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+	uint32_t width = 0, height = 0; // including 2*BUFFER
+	uint32_t n_segments = 0;
+
+	// result.rs:66-76, with the `glyph.y1 -= GLYPH_SIZE` of renderer.rs:146 applied
+	PbfGlyphRef to_pbf(const uint8_t *bitmap) const
+	{
+		PbfGlyphRef g;
+		g.id = id;
+		g.advance = advance;
+		if (has_raster) {
+			g.bitmap = bitmap;
+			g.bitmap_len = (size_t)width * height;
+			g.width = width - 2 * BUFFER;
+			g.height = height - 2 * BUFFER;
+			g.left = x0 + BUFFER;
+			g.top = (y1 - GLYPH_SIZE) - BUFFER;
+		}
+		return g;
+	}
+};
+
+// Host SoA batch in exactly the layout vgsdf_batch wants (include/vgsdf.h).
+struct GlyphBatch {
+	std::vector<GlyphJob> jobs;       // ALL glyphs, rasterised or empty, in submission order
+	std::vector<uint32_t> raster_job; // index into jobs for each rasterised glyph
+	std::vector<uint32_t> seg_off{0};
+	std::vector<double> sx, sy, ex, ey;
+	std::vector<int32_t> x0, y0;
+	std::vector<uint32_t> w, h;
+	std::vector<uint64_t> out_off{0};
+
+	void clear();
+	size_t n_raster() const { return w.size(); }
+	uint64_t out_bytes() const { return out_off.back(); }
+	vgsdf_batch view() const;
+	// appends another batch (jobs keep their relative order)
+	void append(const GlyphBatch &o);
+};
+
+// Per-thread scratch so tessellation allocates nothing in steady state.
+struct TessScratch {
+	RingBuilder builder;
+};
+
+class Renderer {
+public:
+	enum class Mode { Hip, Dummy };
+
+	// renderer.rs:25-31
+	static std::shared_ptr<Renderer> create(bool dummy, int device = 0, std::string *err = nullptr);
+	static std::shared_ptr<Renderer> new_precise(int device = 0, std::string *err = nullptr); // HIP back-end
+	static std::shared_ptr<Renderer> new_dummy();
+	~Renderer();
+
+	Mode mode() const { return mode_; }
+	int device() const { return device_; }
+
+	// Host half of render_glyph, renderer.rs:103-137: cmap lookup, outline, flatten, scale,
+	// sub-pixel shift, bbox + buffer.  nullopt = the reference returns None (glyph skipped).
+	// Rasterised glyphs get their segments appended to `batch`.
+	static bool prepare(const Face &face, uint32_t index, TessScratch &scratch, GlyphBatch &batch);
+
+	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one
+	// vgsdf_render_batch call; Dummy: zeros (renderer_dummy.rs).  Throws std::runtime_error.
+	void render_batch(const GlyphBatch &batch, uint8_t *out) const;
+
+	// renderer.rs:103 — per-glyph API kept for drop-in parity (a batch of one).
+	std::optional<PbfGlyph> render_glyph(const Face &face, uint32_t index) const;
+
+	vgsdf_ctx *ctx() const { return ctx_; }
+	std::mutex &ctx_mutex() const { return mu_; }
+
+private:
+	Renderer() = default;
+	Mode mode_ = Mode::Dummy;
+	int device_ = 0;
+	vgsdf_ctx *ctx_ = nullptr;
+	mutable std::mutex mu_; // vgsdf_ctx is single-threaded
+};
+
+} // namespace vg

@@ -1,0 +1,89 @@
+// ttf_face.hpp — the slice of ttf_parser::Face (crate ttf-parser 0.25.1, a third-party
+// dependency of the reference, not vendored under /root/reference) that the render path
+// calls:
+//   Face::glyph_index        /root/reference/src/render/renderer.rs:106
+//   Face::units_per_em       renderer.rs:107
+//   Face::outline_glyph      renderer.rs:110   (glyf outlines -> OutlineBuilder callbacks)
+//   Face::glyph_hor_advance  renderer.rs:115
+//   cmap subtable walk       src/font/metadata.rs:105-117 (code point coverage)
+// Static TrueType (`glyf`) fonts only; CFF / variable fonts are out of scope (none in the
+// reference's testdata) and are reported as "no outline".
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <optional>
+#include <vector>
+
+namespace vg {
+
+// ttf_parser::OutlineBuilder — f32 font units
+struct OutlineBuilder {
+	virtual ~OutlineBuilder() = default;
+	virtual void move_to(float x, float y) = 0;
+	virtual void line_to(float x, float y) = 0;
+	virtual void quad_to(float x1, float y1, float x, float y) = 0;
+	virtual void curve_to(float x1, float y1, float x2, float y2, float x, float y) = 0;
+	virtual void close() = 0;
+};
+
+// Non-owning big-endian byte view with checked reads.
+class Bytes {
+public:
+	Bytes() = default;
+	Bytes(const uint8_t *p, size_t n) : p_(p), n_(n) {}
+	size_t size() const { return n_; }
+	bool empty() const { return n_ == 0; }
+	const uint8_t *data() const { return p_; }
+	bool has(size_t off, size_t len) const { return off <= n_ && len <= n_ - off; }
+	uint8_t u8(size_t off) const { return p_[off]; }
+	uint16_t u16(size_t off) const { return (uint16_t)((p_[off] << 8) | p_[off + 1]); }
+	int16_t i16(size_t off) const { return (int16_t)u16(off); }
+	uint32_t u32(size_t off) const
+	{
+		return ((uint32_t)p_[off] << 24) | ((uint32_t)p_[off + 1] << 16) | ((uint32_t)p_[off + 2] << 8) |
+		       (uint32_t)p_[off + 3];
+	}
+	Bytes sub(size_t off, size_t len) const { return has(off, len) ? Bytes(p_ + off, len) : Bytes(); }
+	Bytes from(size_t off) const { return off <= n_ ? Bytes(p_ + off, n_ - off) : Bytes(); }
+
+private:
+	const uint8_t *p_ = nullptr;
+	size_t n_ = 0;
+};
+
+class Face {
+public:
+	// Face::parse(data, 0).  The bytes must outlive the Face.
+	static std::optional<Face> parse(const uint8_t *data, size_t len);
+
+	uint16_t units_per_em() const { return units_per_em_; }
+	uint16_t number_of_glyphs() const { return num_glyphs_; }
+	std::optional<uint16_t> glyph_index(uint32_t code_point) const;
+	std::optional<uint16_t> glyph_hor_advance(uint16_t glyph_id) const;
+	// Emits the glyph's outline; returns false when ttf-parser would return None
+	// (callbacks already delivered stay delivered, as in the crate).
+	bool outline_glyph(uint16_t glyph_id, OutlineBuilder &builder) const;
+	// Sorted unique code points that a unicode cmap subtable maps to a glyph.
+	std::vector<uint32_t> unicode_codepoints() const;
+
+private:
+	struct CmapSubtable {
+		uint16_t platform = 0, encoding = 0, format = 0xFFFF;
+		Bytes data; // from the subtable start to the end of the cmap table
+		bool is_unicode() const;
+		std::optional<uint16_t> glyph_index(uint32_t cp) const;
+		template <class F> void for_each_codepoint(F &&f) const;
+	};
+
+	std::optional<Bytes> glyph_data(uint16_t glyph_id) const;
+
+	Bytes hmtx_, loca_, glyf_;
+	std::vector<CmapSubtable> cmap_;
+	uint16_t units_per_em_ = 0, num_glyphs_ = 0, num_hmetrics_ = 0;
+	bool loca_long_ = false;
+	size_t loca_entries_ = 0;
+
+	friend struct GlyfWalker;
+};
+
+} // namespace vg

@@ -1,0 +1,298 @@
+"""ctypes binding of include/vgfont.h: FontManager / Renderer / GlyphBlock façade (C++).
+
+Mirrors the reference's names (src/font/manager.rs, src/render/renderer.rs) so tests read
+like the reference's own tests.  HIP mode has no CPU fallback; Renderer.new_precise()
+raises when no MI355X/HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from .device import Batch, VgsdfError, _CBatch, load_library
+
+MODE_HIP, MODE_DUMMY = 0, 1
+
+
+class PbfGlyph(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("has_bitmap", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("left", C.c_int32), ("top", C.c_int32), ("advance", C.c_uint32), ("bitmap_len", C.c_uint32)]
+    bitmap = None  # numpy u8 [height+6, width+6] or None
+
+    def metrics(self):
+        return (self.width, self.height, self.left, self.top, self.advance)
+
+
+class Timings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("tessellate_s", "device_s", "encode_s", "write_s", "total_s")] + \
+               [(k, C.c_uint64) for k in ("blocks", "glyphs", "rasters", "pixels", "segments", "pbf_bytes")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_int)
+
+VGFONT_SYMBOLS = [
+    "vg_last_error", "vg_renderer_new", "vg_renderer_free", "vg_manager_new", "vg_manager_free",
+    "vg_manager_set_threads", "vg_manager_add_font_with_name", "vg_manager_add_font_data", "vg_manager_add_path",
+    "vg_name_to_id", "vg_manager_block_counts", "vg_manager_render_glyphs", "vg_manager_timings",
+    "vg_manager_render_block", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
+    "vg_glyph_batch_free", "vg_pbf_encode",
+]
+
+_bound = False
+
+
+def _L():
+    global _bound
+    L = load_library()
+    if not _bound:
+        vp = C.c_void_p
+        L.vg_last_error.restype = C.c_char_p
+        L.vg_renderer_new.restype = vp
+        L.vg_renderer_new.argtypes = [C.c_int, C.c_int]
+        L.vg_renderer_free.argtypes = [vp]
+        L.vg_manager_new.restype = vp
+        L.vg_manager_new.argtypes = [C.c_int]
+        L.vg_manager_free.argtypes = [vp]
+        L.vg_manager_set_threads.argtypes = [vp, C.c_uint, C.c_uint]
+        L.vg_manager_add_font_with_name.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+        L.vg_manager_add_font_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.vg_manager_add_path.argtypes = [vp, C.c_char_p]
+        L.vg_name_to_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.vg_manager_block_counts.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32)]
+        L.vg_manager_render_glyphs.argtypes = [vp, vp, WRITE_CB, vp]
+        L.vg_manager_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.vg_manager_render_block.restype = C.c_long
+        L.vg_manager_render_block.argtypes = [vp, vp, C.c_char_p, C.c_uint32, vp, C.c_size_t]
+        L.vg_render_glyph.argtypes = [vp, vp, C.c_char_p, C.c_int, C.c_uint32, C.POINTER(PbfGlyph), vp, C.c_size_t]
+        L.vg_manager_build_batch.restype = vp
+        L.vg_manager_build_batch.argtypes = [vp, C.c_char_p]
+        L.vg_glyph_batch_view.argtypes = [vp, C.POINTER(_CBatch), C.POINTER(C.POINTER(C.c_uint32)),
+                                          C.POINTER(C.c_uint32)]
+        L.vg_glyph_batch_free.argtypes = [vp]
+        L.vg_pbf_encode.restype = C.c_long
+        L.vg_pbf_encode.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PbfGlyph), C.POINTER(C.c_void_p), C.c_int,
+                                    vp, C.c_size_t]
+        _bound = True
+    return L
+
+
+def _err() -> str:
+    return (_L().vg_last_error() or b"").decode()
+
+
+def name_to_id(name: str) -> str:
+    buf = C.create_string_buffer(1024)
+    _L().vg_name_to_id(name.encode(), buf, len(buf))
+    return buf.value.decode()
+
+
+class Renderer:
+    """src/render/renderer.rs Renderer; Precise == the HIP back-end."""
+
+    def __init__(self, handle, mode):
+        self._h, self.mode = handle, mode
+
+    @classmethod
+    def new(cls, dummy: bool, device: int = 0):
+        return cls.new_dummy() if dummy else cls.new_precise(device)
+
+    @classmethod
+    def new_precise(cls, device: int = 0):
+        h = _L().vg_renderer_new(MODE_HIP, device)
+        if not h:
+            raise VgsdfError(-2, _err())
+        return cls(h, MODE_HIP)
+
+    @classmethod
+    def new_dummy(cls):
+        return cls(_L().vg_renderer_new(MODE_DUMMY, 0), MODE_DUMMY)
+
+    def render_glyph(self, manager: "FontManager", font_id: str, index: int, file_index: int = 0):
+        """Renderer::render_glyph(&face, index) -> PbfGlyph | None"""
+        g = PbfGlyph()
+        buf = np.empty(1 << 20, dtype=np.uint8)
+        rc = _L().vg_render_glyph(self._h, manager._h, font_id.encode(), file_index, index, C.byref(g),
+                                  buf.ctypes.data, buf.size)
+        if rc < 0:
+            raise RuntimeError(_err())
+        if rc == 0:
+            return None
+        if g.has_bitmap:
+            g.bitmap = buf[:g.bitmap_len].reshape(g.height + 6, g.width + 6).copy()
+        return g
+
+    def close(self):
+        if self._h:
+            _L().vg_renderer_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GlyphBatchHost:
+    """Owner of a host SoA batch produced by the C++ tessellation stage."""
+
+    def __init__(self, handle):
+        self._h = handle
+        cb = _CBatch()
+        ids = C.POINTER(C.c_uint32)()
+        nj = C.c_uint32(0)
+        _L().vg_glyph_batch_view(handle, C.byref(cb), C.byref(ids), C.byref(nj))
+        n = cb.n_glyphs
+        self.n_jobs = nj.value
+
+        def arr(ptr, count, dt):
+            if count == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt, count=count)
+
+        seg_off = arr(cb.seg_off, n + 1, np.uint32)
+        s = int(seg_off[-1]) if n else 0
+        self.batch = Batch(seg_off, arr(cb.seg_sx, s, np.float64), arr(cb.seg_sy, s, np.float64),
+                           arr(cb.seg_ex, s, np.float64), arr(cb.seg_ey, s, np.float64), arr(cb.x0, n, np.int32),
+                           arr(cb.y0, n, np.int32), arr(cb.w, n, np.uint32), arr(cb.h, n, np.uint32),
+                           arr(cb.out_off, n + 1, np.uint64))
+        self.ids = arr(C.cast(ids, C.c_void_p).value, n, np.uint32)
+
+    def free(self):
+        if self._h:
+            _L().vg_glyph_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FontManager:
+    """src/font/manager.rs FontManager (render path only)."""
+
+    def __init__(self, parallel: bool = True):
+        self._h = _L().vg_manager_new(1 if parallel else 0)
+        self._cb_keepalive = None
+
+    def set_threads(self, threads: int = 0, blocks_per_batch: int = 0):
+        _L().vg_manager_set_threads(self._h, threads, blocks_per_batch)
+
+    def add_font_with_name(self, name: str, sources):
+        paths = [str(Path(p)).encode() for p in sources]
+        arr = (C.c_char_p * len(paths))(*paths)
+        if _L().vg_manager_add_font_with_name(self._h, name.encode(), arr, len(paths)) != 0:
+            raise RuntimeError(_err())
+        return name_to_id(name)
+
+    def add_font_data(self, name: str, data: bytes):
+        if _L().vg_manager_add_font_data(self._h, name.encode(), data, len(data)) != 0:
+            raise RuntimeError(_err())
+        return name_to_id(name)
+
+    def add_path(self, path):
+        if _L().vg_manager_add_path(self._h, str(path).encode()) != 0:
+            raise NotImplementedError(_err())
+
+    def block_counts(self, font_id: str) -> np.ndarray:
+        out = np.zeros(256, dtype=np.uint32)
+        if _L().vg_manager_block_counts(self._h, font_id.encode(), out.ctypes.data_as(C.POINTER(C.c_uint32))) != 0:
+            raise KeyError(_err())
+        return out
+
+    def render_glyphs(self, writer, renderer: Renderer):
+        """FontManager::render_glyphs(&mut writer, &renderer).  `writer` needs
+        write_directory(path) and write_file(path, bytes)."""
+        errors = []
+
+        def cb(_user, path, data, n, is_dir):
+            try:
+                if is_dir:
+                    writer.write_directory(path.decode())
+                else:
+                    writer.write_file(path.decode(), C.string_at(data, n) if n else b"")
+                return 0
+            except Exception as e:  # propagate through the C boundary as an abort
+                errors.append(e)
+                return 1
+
+        ccb = WRITE_CB(cb)
+        rc = _L().vg_manager_render_glyphs(self._h, renderer._h, ccb, None)
+        if errors:
+            raise errors[0]
+        if rc != 0:
+            raise RuntimeError(_err())
+
+    def timings(self) -> dict:
+        t = Timings()
+        _L().vg_manager_timings(self._h, C.byref(t))
+        return t.as_dict()
+
+    def render_block(self, renderer: Renderer, font_id: str, start: int) -> bytes:
+        """GlyphBlock::render(font_name, renderer) for block `start`."""
+        need = _L().vg_manager_render_block(self._h, renderer._h, font_id.encode(), start, None, 0)
+        if need < 0:
+            raise RuntimeError(_err())
+        out = np.empty(need, dtype=np.uint8)
+        got = _L().vg_manager_render_block(self._h, renderer._h, font_id.encode(), start, out.ctypes.data, need)
+        if got != need:
+            raise RuntimeError(_err())
+        return out.tobytes()
+
+    def build_batch(self, font_id: str) -> GlyphBatchHost:
+        h = _L().vg_manager_build_batch(self._h, font_id.encode())
+        if not h:
+            raise RuntimeError(_err())
+        return GlyphBatchHost(h)
+
+    def close(self):
+        if self._h:
+            _L().vg_manager_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DummyWriter:
+    """src/writer/dummy.rs: records 'name (len)' strings; keeps the bytes too."""
+
+    def __init__(self):
+        self.inner, self.files = [], {}
+
+    def write_directory(self, path):
+        self.inner.append(path)
+
+    def write_file(self, path, data):
+        self.inner.append(f"{path} ({len(data)})")
+        self.files[path] = data
+
+
+def pbf_encode(name: str, range_: str, glyphs) -> bytes:
+    """glyphs: [PbfGlyph] (bitmap attribute used when has_bitmap)."""
+    n = len(glyphs)
+    arr = (PbfGlyph * max(n, 1))()
+    ptrs = (C.c_void_p * max(n, 1))()
+    keep = []
+    for i, g in enumerate(glyphs):
+        arr[i] = g
+        if g.has_bitmap and g.bitmap is not None:
+            b = np.ascontiguousarray(g.bitmap, dtype=np.uint8)
+            keep.append(b)
+            arr[i].bitmap_len = b.size
+            ptrs[i] = b.ctypes.data
+    need = _L().vg_pbf_encode(name.encode(), range_.encode(), arr, ptrs, n, None, 0)
+    out = np.empty(need, dtype=np.uint8)
+    _L().vg_pbf_encode(name.encode(), range_.encode(), arr, ptrs, n, out.ctypes.data, need)
+    return out.tobytes()
