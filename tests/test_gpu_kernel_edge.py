@@ -1,0 +1,147 @@
+"""GPU: adversarial and synthetic inputs straight at the C ABI (vgsdf_render_batch), both
+kernel variants (0 = filtered, 1 = brute force) against the oracle.  Covers what the font
+fixtures do not: ties, degenerate segments, winding +-2, samples exactly on vertices / rows,
+queue overflow, multi-chunk segment lists, wide / thin rects, big coordinates."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    c = vg.SdfContext(0)
+    yield c
+    c.close()
+
+
+def ring(points):
+    p = np.asarray(points, dtype=np.float64)
+    return np.concatenate([p, np.roll(p, -1, axis=0)], axis=1)
+
+
+def run_both(oracle, vg, ctx, glyphs, mode=None):
+    """glyphs: [(segs, x0, y0, w, h)] -> asserts both variants equal the oracle"""
+    batch = vg.make_batch(glyphs)
+    want, _ = oracle.sdf_render_batch(batch, oracle.BRUTE if mode is None else mode, 4)
+    for variant in (0, 1):
+        ctx.set_variant(variant)
+        got = ctx.render_batch(batch)
+        diff = np.flatnonzero(got != want)
+        assert diff.size == 0, f"variant {variant}: {diff.size} bytes differ, first at {diff[:5]}"
+    ctx.set_variant(0)
+    return batch, want
+
+
+def random_polys(rng, n_glyphs, n_rings, n_pts, size, jitter=0.35):
+    out = []
+    for _ in range(n_glyphs):
+        segs = []
+        for k in range(n_rings):
+            c = rng.uniform(size * 0.25, size * 0.75, 2)
+            r0 = rng.uniform(size * 0.08, size * 0.35)
+            a = np.sort(rng.uniform(0, 2 * np.pi, n_pts))
+            r = r0 * (1 + jitter * rng.uniform(-1, 1, n_pts))
+            pts = np.stack([c[0] + r * np.cos(a), c[1] + r * np.sin(a)], 1)
+            if k % 2:
+                pts = pts[::-1]
+            segs.append(ring(pts))
+        segs = np.concatenate(segs)
+        lo = np.floor(segs[:, [0, 1]].min(0)).astype(int) - 3
+        hi = np.ceil(segs[:, [0, 1]].max(0)).astype(int) + 3
+        out.append((segs, int(lo[0]), int(lo[1]), int(hi[0] - lo[0]), int(hi[1] - lo[1])))
+    return out
+
+
+def test_random_polygons_small(oracle, vg, ctx):
+    rng = np.random.default_rng(1)
+    run_both(oracle, vg, ctx, random_polys(rng, 40, 3, 40, 30))
+
+
+def test_random_polygons_multichunk(oracle, vg, ctx):
+    # N = 2600 and 5200 segments: 3 and 6 LDS chunks of the filtered kernel
+    rng = np.random.default_rng(2)
+    run_both(oracle, vg, ctx, random_polys(rng, 3, 2, 1300, 50) + random_polys(rng, 2, 4, 1300, 60))
+
+
+def test_overlapping_rings_winding(oracle, vg, ctx):
+    sq = lambda a, b: [(a, a), (b, a), (b, b), (a, b)]  # noqa: E731
+    ccw = ring(sq(2, 12))
+    ccw2 = ring(sq(6, 16))
+    cw = ring(sq(6, 16)[::-1])
+    glyphs = [
+        (np.concatenate([ccw, ccw2]), -1, -1, 20, 20),   # winding 2 in the overlap
+        (np.concatenate([ccw, cw]), -1, -1, 20, 20),     # winding 0 in the overlap (XOR-like)
+        (np.concatenate([ccw, ccw, ccw]), -1, -1, 16, 16),  # identical rings: ties everywhere
+    ]
+    run_both(oracle, vg, ctx, glyphs)
+
+
+def test_samples_on_vertices_and_rows(oracle, vg, ctx):
+    # vertices exactly on pixel centres (x.5), horizontal edges exactly on sample rows,
+    # zero-length segments, a vertex repeated
+    pts = [(2.5, 2.5), (9.5, 2.5), (9.5, 2.5), (9.5, 7.5), (6.5, 7.5), (6.5, 4.5), (2.5, 4.5)]
+    segs = ring(pts)
+    segs = np.concatenate([segs, [[4.5, 3.5, 4.5, 3.5]]])  # isolated degenerate segment
+    run_both(oracle, vg, ctx, [(segs, 0, 0, 13, 11), (segs, -3, -2, 19, 15)])
+    run_both(oracle, vg, ctx, [(segs, 0, 0, 13, 11)], mode=oracle.PRECISE)
+
+
+def test_many_ties_queue_overflow(oracle, vg, ctx):
+    # 3000 copies of one small triangle: every segment copy ties -> >2048 survivors per tile
+    tri = ring([(3, 3), (9, 4), (5, 9)])
+    segs = np.tile(tri, (3000, 1))
+    run_both(oracle, vg, ctx, [(segs, 0, 0, 12, 12)])
+
+
+def test_wide_and_thin_rects(oracle, vg, ctx):
+    rng = np.random.default_rng(3)
+    wide = ring(np.stack([np.linspace(5, 1500, 60), 6 + 3 * np.sin(np.linspace(0, 20, 60))], 1).tolist()
+                + [(1500, 14), (5, 14)])
+    thin = ring(np.stack([3 + 0.8 * np.sin(np.linspace(0, 9, 50)), np.linspace(4, 400, 50)], 1).tolist()
+                + [(5.5, 400), (5.5, 4)])
+    glyphs = [
+        (wide, 0, 0, 1510, 20),    # w > 1023: histogram does not fit -> brute-force route
+        (wide, 0, 0, 900, 20),     # clipped rect, filtered route, 2 rows per tile
+        (thin, 0, 0, 7, 410),      # 7 px wide: 38 rows per tile
+        (thin, -40, -40, 60, 30),  # rect mostly away from the outline
+    ]
+    run_both(oracle, vg, ctx, glyphs)
+
+
+def test_big_and_far_coordinates(oracle, vg, ctx):
+    rng = np.random.default_rng(4)
+    base = random_polys(rng, 2, 2, 60, 24)
+    glyphs = []
+    for segs, x0, y0, w, h in base:
+        for off in (1.0e4, 3.0e6 + 0.25, -7.0e8):
+            s = segs.copy()
+            s[:, [0, 2]] += off
+            glyphs.append((s, x0 + int(np.floor(off)), y0, w, h))
+        # segments far outside the rect (relative coordinates ~1e7: no usable f32 bound)
+        glyphs.append((np.concatenate([segs, segs + 1.0e7]), x0, y0, w, h))
+    run_both(oracle, vg, ctx, glyphs)
+
+
+def test_synthetic_first_outlines(oracle, vg, ctx):
+    from versatiles_glyphs_rs_amd import synthetic as S
+    batch = S.make_batch(0, 48)
+    want, _ = oracle.sdf_render_batch(batch, oracle.PRECISE, 4)
+    for variant in (0, 1):
+        ctx.set_variant(variant)
+        assert np.array_equal(ctx.render_batch(batch), want)
+    ctx.set_variant(0)
+
+
+def test_empty_and_tiny_batches(oracle, vg, ctx):
+    assert ctx.render_batch(vg.make_batch([])).size == 0
+    tri = ring([(1, 1), (3, 1), (2, 3)])
+    run_both(oracle, vg, ctx, [(tri, 0, 0, 1, 1), (tri, 0, 0, 4, 4), (tri[:0], 0, 0, 3, 3)])
+
+
+def test_argument_validation(vg, ctx):
+    b = vg.make_batch([(ring([(1, 1), (3, 1), (2, 3)]), 0, 0, 4, 4)])
+    b.out_off[1] = 15  # inconsistent with w*h
+    with pytest.raises(vg.VgsdfError) as e:
+        ctx.render_batch(b)
+    assert e.value.code == -1

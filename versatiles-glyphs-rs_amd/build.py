@@ -1,4 +1,5 @@
 """In-tree build of libvgsdf.so (hipcc, --offload-arch=gfx950)."""
+import os
 import subprocess
 from pathlib import Path
 
@@ -6,7 +7,8 @@ PKG = Path(__file__).resolve().parent
 
 
 def lib_path() -> Path:
-    return PKG / "libvgsdf.so"
+    # VGSDF_LIB: A/B experiments with alternative in-tree builds (development only)
+    return Path(os.environ["VGSDF_LIB"]) if os.environ.get("VGSDF_LIB") else PKG / "libvgsdf.so"
 
 
 def build(force: bool = False) -> Path:

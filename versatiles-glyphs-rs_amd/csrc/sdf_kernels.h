@@ -20,6 +20,9 @@ static_assert(sizeof(GlyphDesc) == 32, "GlyphDesc must stay 32 bytes");
 
 } // namespace vgsdf
 
+// largest rows*(w+1) a tile of the filtered kernel may need (winding histogram in LDS)
+extern "C" int vgsdf_filtered_delta_cap(void);
+
 // tiles[i] = (glyph index, first output byte of the tile inside that glyph's bitmap)
 extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, const uint2 *tiles,
                                   uint32_t n_tiles, const double *sx, const double *sy,

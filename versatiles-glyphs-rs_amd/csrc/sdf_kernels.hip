@@ -53,6 +53,25 @@ __device__ __forceinline__ uint8_t quantise(double best_sq, bool inside)
 	return (uint8_t)(int)round(n);       // :79  half away from zero
 }
 
+// Exact squared distance from p to segment (v,w): Segment::squared_distance_to_point,
+// segment.rs:54-72,96-99 with Point::squared_distance_to, point.rs:38-42.  dx,dy,l2 are the
+// reference's (w.x - v.x), (w.y - v.y) and v.squared_distance_to(w), bit for bit.
+__device__ __forceinline__ double exact_dist_sq(double px, double py, double vx, double vy, double wx,
+                                                double wy, double dx, double dy, double l2)
+{
+	const double pvx = px - vx, pvy = py - vy;
+	const double t = (pvx * dx + pvy * dy) / l2; // NaN when l2 == 0 (0/0): masked by at_v below
+	double qx = vx + t * dx, qy = vy + t * dy;
+	const bool at_v = (l2 == 0.0) | (t < 0.0); // segment.rs:59-61, :65-66
+	const bool at_w = t > 1.0;                 // :67-68
+	qx = at_w ? wx : qx;
+	qy = at_w ? wy : qy;
+	qx = at_v ? vx : qx;
+	qy = at_v ? vy : qy;
+	const double ex = qx - px, ey = qy - py; // point.rs:39-40 (other - self)
+	return ex * ex + ey * ey;
+}
+
 // ---------------------------------------------------------------------------------------
 // Variant 1: brute force.  Every pixel evaluates every segment.
 // ---------------------------------------------------------------------------------------
@@ -105,18 +124,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
 			const double vx = s_vx[i], vy = s_vy[i], wx = s_wx[i], wy = s_wy[i];
 			const double dx = s_dx[i], dy = s_dy[i], l2 = s_l2[i];
 
-			// --- distance: segment.rs:54-72 ---
-			const double pvx = px - vx, pvy = py - vy;
-			const double t = (pvx * dx + pvy * dy) / l2; // NaN when l2 == 0 (0/0) — see below
-			double qx = vx + t * dx, qy = vy + t * dy;
-			const bool at_v = (l2 == 0.0) | (t < 0.0);   // :59-61, :65-66
-			const bool at_w = t > 1.0;                   // :67-68
-			qx = at_w ? wx : qx;
-			qy = at_w ? wy : qy;
-			qx = at_v ? vx : qx;
-			qy = at_v ? vy : qy;
-			const double ex = qx - px, ey = qy - py;     // point.rs:39-40 (other - self)
-			const double d2 = ex * ex + ey * ey;
+			const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, l2);
 			best = d2 < best ? d2 : best;                // rtree_segments.rs:60-62
 
 			// --- winding: renderer_precise.rs:41-51, 63-66 ---
@@ -135,11 +143,263 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
 		out[g.out_off + o] = quantise(best, wn != 0);
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 0 (default): filtered, single pass.  Same bytes as brute force, ~N/2 fewer exact
+// evaluations per pixel.
+//
+//   filter  every (pixel, segment) pair is evaluated in f32 (9 VALU ops) with coordinates
+//           relative to the glyph origin.  The value F is packed with the segment's index
+//           into one 32-bit key (F >= +0, so unsigned order of the bits is float order; the
+//           low IDX_BITS mantissa bits carry the index) and inserted into a per-lane sorted
+//           top-4 with v_min_u32 + 3 x v_med3_u32.  15 VALU ops per pair, no branches.
+//   exact   after a chunk, the best candidate and every other top-4 candidate that cannot be
+//           EXCLUDED (see below) are evaluated in f64 with the reference's exact operation
+//           order, straight from LDS.  If even the 4th candidate cannot be excluded the lane
+//           rescans the chunk against a verified key threshold (rare: >= 4 near-ties).
+//   sign    per (segment, row) crossing -> a per-row column histogram in LDS (what the
+//           reference's sorted crossing sweep computes, renderer_precise.rs:41-67); prefix
+//           sums give the winding number of every pixel.  Exact f64 compares only.
+//
+// Why it is exact.  C(p,s): the reference's f64 value; D: the real value; Ft: the f32 value;
+// Fk <= Ft <= Fk (1 + 2^-14): the key's truncated value.  With |Ft - D| <= h(Ft) and
+// |C - D| <= e64 (bounds derived in DESIGN.md):
+//      min_s C  <=  C(s1)  <=  U := Fk1 (1+2^-14) + h(Fk1 (1+2^-14)) + e64        (s1 = smallest key)
+//      C(s)     >=  L(s) := Fk(s) - h(Fk(s) (1+2^-14)) - e64.
+// A segment with L(s) > U can therefore not attain the minimum; L is increasing in Fk on
+// the range where that can happen, so once the k-th smallest key is excluded all larger keys
+// are.  The minimum of C over the non-excluded segments is the minimum over all segments,
+// bit for bit.  Non-finite inputs or |coordinates| >= 1e6 px make U = +inf (nothing is
+// excluded, the lane rescans everything exactly).
+// ---------------------------------------------------------------------------------------
+constexpr int IDX_BITS = 8;
+constexpr int FCHUNK = 1 << IDX_BITS; // 512 segments per LDS stage: 20 B filter + 32 B exact each
+constexpr uint32_t IDX_MASK = FCHUNK - 1;
+constexpr int DELTA_CAP = 2048;       // winding histogram cells per tile: rows * (w + 1)
+constexpr float KEY_SLACK = 1.0f + 2.0f / (float)(1 << (23 - IDX_BITS)) * 0.5f + 1.0f / 4194304.0f; // >= (1 + 2^-(23-IDX_BITS))(1 + 2^-23)
+
+// smallest integer n in [A, B] with (double)n + c >= v   (B if none): exact f64 compares
+__device__ __forceinline__ int first_ge(double v, double c, int A, int B)
+{
+	double a = ceil(v - c);
+	a = a < (double)A ? (double)A : a;
+	a = a > (double)B ? (double)B : a; // NaN ends up inside [A, B] too; the compares below are then false
+	int n = (int)a;
+	if (n > A && (double)(n - 1) + c >= v)
+		n--;
+	else if (n < B && (double)n + c < v)
+		n++;
+	return n;
+}
+
+// f32 filter: squared distance from the pixel centre (rpx,rpy) to the segment starting at
+// (a.x,a.y) with UNIT direction (a.z,a.w) and length len — all relative to the glyph origin.
+__device__ __forceinline__ float filter_dist_sq(float rpx, float rpy, float4 a, float len)
+{
+	const float pvx = rpx - a.x, pvy = rpy - a.y;
+	const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(pvy, a.w, pvx * a.z), 0.0f, len);
+	const float ex = __builtin_fmaf(-t, a.z, pvx), ey = __builtin_fmaf(-t, a.w, pvy);
+	return __builtin_fmaf(ey, ey, ex * ex);
+}
+
+// median of three unsigned values: one v_med3_u32
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+
+// h(F): bound on |Ft - D| for a filter value F, coordinates bounded by M:
+// 64 u M sqrt(F) + 32 u F + 2^-34 M^2 with u = 2^-24, evaluated with upward slack.
+__device__ __forceinline__ float filter_err(float F, float M)
+{
+	return 1.001f * (3.814697265625e-06f * M * __builtin_sqrtf(F) + 1.9073486328125e-06f * F +
+	                 5.820766091346741e-11f * M * M);
+}
+
+// ABL: timing-only ablation mask (0 in production; non-zero variants give WRONG pixels):
+// 1 no winding pass, 2 no filter loop, 4 no exact evaluation, 16 no prefix loop
+template <int ABL>
+__global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__restrict__ glyphs,
+                                                          const uint2 *__restrict__ tiles,
+                                                          uint32_t n_tiles,
+                                                          const double *__restrict__ seg_sx,
+                                                          const double *__restrict__ seg_sy,
+                                                          const double *__restrict__ seg_ex,
+                                                          const double *__restrict__ seg_ey,
+                                                          uint8_t *__restrict__ out)
+{
+	__shared__ float4 s_f[FCHUNK];  // (vx, vy, nx, ny) f32: start relative to (x0, y0), unit direction
+	__shared__ __attribute__((aligned(16))) float s_len[FCHUNK]; // segment length; direction (0,0) and length 0 when degenerate
+	__shared__ double s_vx[FCHUNK], s_vy[FCHUNK], s_wx[FCHUNK], s_wy[FCHUNK]; // exact endpoints
+	__shared__ int s_delta[DELTA_CAP];
+	__shared__ uint32_t s_mbits;
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
+	const uint2 t = tiles[tile];
+	const GlyphDesc g = glyphs[t.x];
+	const uint32_t npix = g.w * g.h;
+	const uint32_t o = t.y + tid;
+	const bool active = o < npix;
+	const uint32_t oc = active ? o : npix - 1;
+	const uint32_t row = oc / g.w;
+	const uint32_t x = oc - row * g.w;
+	const uint32_t y = g.h - 1 - row;
+	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
+	const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
+	const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
+
+	// rows of the bitmap this tile touches: output rows [r_first, r_last] = y in [y_lo, y_hi]
+	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
+	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
+	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
+	const uint32_t stride = g.w + 1;
+	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
+
+	for (uint32_t i = tid; i < n_delta; i += TPB)
+		s_delta[i] = 0;
+
+	const float wh = (float)max(g.w, g.h);
+	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
+	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
+	double best = __builtin_huge_val(); // rtree_segments.rs:57
+
+	auto exact_lds = [&](uint32_t i) {
+		const double vx = s_vx[i], vy = s_vy[i], wx = s_wx[i], wy = s_wy[i];
+		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
+		const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
+		best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
+	};
+
+	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
+		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
+		__syncthreads(); // previous chunk fully consumed (and s_delta zeroed on the first trip)
+		if (tid == 0)
+			s_mbits = __float_as_uint(wh);
+		__syncthreads();
+
+		// ---- stage: exact endpoints, f32 filter data, coordinate bound, row crossings ----
+		for (uint32_t i = tid; i < cnt; i += TPB) {
+			const uint32_t s = g.seg_off + c0 + i;
+			const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
+			s_vx[i] = vx;
+			s_vy[i] = vy;
+			s_wx[i] = wx;
+			s_wy[i] = wy;
+			const double dx = wx - vx, dy = wy - vy;
+			const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
+			const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
+			const float len = (float)sqrt(dx * dx + dy * dy);
+			const bool ok = len > 1e-12f && len < 1e30f;
+			const float rl = ok ? 1.0f / len : 0.0f;
+			s_f[i] = make_float4((float)rvx, (float)rvy, (float)dx * rl, (float)dy * rl);
+			s_len[i] = ok ? len : 0.0f;
+			const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
+			float mf = (float)m * 1.000001f;                // round up
+			mf = mf >= 0.0f ? mf : __builtin_inff();        // NaN -> inf ("no usable bound")
+			atomicMax(&s_mbits, __float_as_uint(mf));       // non-negative floats order like uints
+			// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
+			if (!(ABL & 1) && vy != wy) {
+				const bool up = vy < wy;
+				const double lo = up ? vy : wy, hi = up ? wy : vy;
+				const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
+				const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
+				for (int yy = ya; yy < yb; yy++) {
+					const double pyy = (double)yy + y0c;
+					const double tc = (pyy - vy) / dy;
+					const double xc = vx + tc * dx;               // :45-46 / :48-49
+					const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
+					if (k < (int)g.w)
+						atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
+				}
+			}
+		}
+		__syncthreads();
+
+		// ---- filter: sorted top-3 of (F | index) keys ----
+		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
+		auto consider = [&](float4 a, float len, uint32_t i) {
+			const float F = filter_dist_sq(rpx, rpy, a, len);
+			const uint32_t key = (__float_as_uint(F) & ~IDX_MASK) | (i & IDX_MASK);
+			// insert into the sorted quadruple: clamp(key, k_{j-1}, k_j) = med3
+			k4 = umed3(k3, k4, key);
+			k3 = umed3(k2, k3, key);
+			k2 = umed3(k1, k2, key);
+			k1 = min(k1, key);
+		};
+		const uint32_t cnt_f = (ABL & 2) ? min(cnt, 4u) : cnt;
+		const uint32_t cnt4 = cnt_f & ~3u;
+		const float4 *s_len4 = reinterpret_cast<const float4 *>(s_len);
+		for (uint32_t i = 0; i < cnt4; i += 4) {
+			const float4 a0 = s_f[i], a1 = s_f[i + 1], a2 = s_f[i + 2], a3 = s_f[i + 3];
+			const float4 l = s_len4[i >> 2];
+			consider(a0, l.x, i);
+			consider(a1, l.y, i + 1);
+			consider(a2, l.z, i + 2);
+			consider(a3, l.w, i + 3);
+		}
+		for (uint32_t i = cnt4; i < cnt_f; i++)
+			consider(s_f[i], s_len[i], i);
+
+		if (!(ABL & 4)) {
+			// ---- exact evaluation of the candidates that cannot be excluded ----
+			const float M = __uint_as_float(s_mbits);
+			const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
+			const float f1 = __uint_as_float(k1 & ~IDX_MASK) * KEY_SLACK;
+			float U = f1 + filter_err(f1, M) + e64;
+			if (!(M < 1.0e6f) || !(U >= 0.0f))
+				U = __builtin_inff();
+			auto excluded = [&](uint32_t key) {
+				const float fk = __uint_as_float(key & ~IDX_MASK);
+				return fk - filter_err(fk * KEY_SLACK, M) - e64 > U; // false for NaN / inf U
+			};
+			exact_lds(k1 & IDX_MASK); // cnt >= 1, so k1 is a real key
+			if (cnt >= 2 && !excluded(k2))
+				exact_lds(k2 & IDX_MASK);
+			if (cnt >= 3 && !excluded(k3))
+				exact_lds(k3 & IDX_MASK);
+			if (cnt >= 4 && !excluded(k4)) {
+				exact_lds(k4 & IDX_MASK);
+				// Four near-ties: more may hide behind them.  Rescan the chunk against a
+				// key threshold Tk with L(Tk) > U (L increasing above it): fixed-point
+				// iteration for the crossing, pushed up, then VERIFIED; if the check fails
+				// nothing is excluded (Tk = inf).
+				float Tk = U + e64;
+				for (int it = 0; it < 3; it++)
+					Tk = U + e64 + filter_err(Tk * KEY_SLACK, M);
+				Tk = Tk * 1.001f + 1e-30f;
+				if (!(Tk - filter_err(Tk * KEY_SLACK, M) - e64 > U))
+					Tk = __builtin_inff();
+				for (uint32_t i = 0; i < ((ABL & 8) ? 0u : cnt); i++) {
+					const float F = filter_dist_sq(rpx, rpy, s_f[i], s_len[i]);
+					const float fk = __uint_as_float(__float_as_uint(F) & ~IDX_MASK);
+					if (!(fk > Tk))
+						exact_lds(i);
+				}
+			}
+		}
+	}
+
+	if (active) {
+		// winding number = prefix sum of the row's histogram up to this column
+		int wn = 0;
+		const int *drow = s_delta + (row - r_first) * stride;
+		for (uint32_t k = 0; k <= ((ABL & 16) ? 0u : x); k++)
+			wn += drow[k];
+		out[g.out_off + o] = quantise(best, wn != 0);
+	}
+}
+
 } // namespace vgsdf
 
 // ---------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------
+extern "C" int vgsdf_filtered_delta_cap(void) { return vgsdf::DELTA_CAP; }
+
+// variant 0: filtered kernel; variant 1: brute force (also the fallback for tiles the host
+// routes there: glyphs too wide for the winding histogram, or with >= 2^24 segments).
 extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, const uint2 *tiles,
                                   uint32_t n_tiles, const double *sx, const double *sy,
                                   const double *ex, const double *ey, uint8_t *out,
@@ -147,8 +407,25 @@ extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, c
 {
 	if (n_tiles == 0)
 		return 0;
-	(void)variant;
-	hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, dim3(n_tiles), dim3(vgsdf::TPB), 0, stream, glyphs,
-	                   tiles, n_tiles, sx, sy, ex, ey, out);
+#define VG_LAUNCH_FILTERED(A)                                                                          \
+	hipLaunchKernelGGL(vgsdf::sdf_tiles_filtered<A>, dim3(n_tiles), dim3(vgsdf::TPB), 0, stream, glyphs, \
+	                   tiles, n_tiles, sx, sy, ex, ey, out)
+	if (variant == 1)
+		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, dim3(n_tiles), dim3(vgsdf::TPB), 0, stream, glyphs,
+		                   tiles, n_tiles, sx, sy, ex, ey, out);
+	else if (variant >= 100) { // timing-only ablations 100 + mask
+		switch (variant - 100) {
+		case 1: VG_LAUNCH_FILTERED(1); break;
+		case 2: VG_LAUNCH_FILTERED(2); break;
+		case 4: VG_LAUNCH_FILTERED(4); break;
+		case 6: VG_LAUNCH_FILTERED(6); break;
+		case 8: VG_LAUNCH_FILTERED(8); break;
+		case 16: VG_LAUNCH_FILTERED(16); break;
+		case 23: VG_LAUNCH_FILTERED(23); break;
+		case 22: VG_LAUNCH_FILTERED(22); break;
+		default: VG_LAUNCH_FILTERED(0); break;
+		}
+	} else
+		VG_LAUNCH_FILTERED(0);
 	return (int)hipGetLastError();
 }

@@ -39,6 +39,7 @@ struct vgsdf_dbatch {
 	double *d_sx = nullptr, *d_sy = nullptr, *d_ex = nullptr, *d_ey = nullptr;
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
+	uint32_t n_main = 0; // tiles [0, n_main) go to the filtered kernel, the rest to brute force
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -248,7 +249,29 @@ int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	if (n) {
 		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
 		uint2 *ht = (uint2 *)(hs + off_tiles);
+		// Tiles the filtered kernel can take come first; a glyph goes to the brute-force
+		// kernel when its winding histogram (rows touched by 256 consecutive pixels, times
+		// w+1 columns) would not fit in LDS, or its segment index needs more than 24 bits.
+		const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
+		auto wants_brute = [&](uint32_t g) {
+			const uint64_t w = in->w[g];
+			if (w == 0)
+				return false;
+			const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
+			return rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24);
+		};
 		uint64_t ti = 0;
+		for (int pass = 0; pass < 2; pass++) {
+			for (uint32_t g = 0; g < n; g++) {
+				if ((int)wants_brute(g) != pass)
+					continue;
+				const uint32_t px = in->w[g] * in->h[g];
+				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
+					ht[ti++] = make_uint2(g, p);
+			}
+			if (pass == 0)
+				b->n_main = (uint32_t)ti;
+		}
 		for (uint32_t g = 0; g < n; g++) {
 			hd[g].seg_off = in->seg_off[g];
 			hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
@@ -257,9 +280,6 @@ int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			hd[g].w = in->w[g];
 			hd[g].h = in->h[g];
 			hd[g].out_off = in->out_off[g];
-			const uint32_t px = in->w[g] * in->h[g];
-			for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
-				ht[ti++] = make_uint2(g, p);
 		}
 		if (n_seg) {
 			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
@@ -287,8 +307,13 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_E_ARG;
 	}
 	(void)hipSetDevice(ctx->device);
-	int e = vgsdf_launch_tiles(ctx->variant, b->d_glyphs, b->d_tiles, (uint32_t)b->stats.n_tiles, b->d_sx,
-	                           b->d_sy, b->d_ex, b->d_ey, b->d_out, ctx->stream);
+	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
+	const uint32_t n_main = ctx->variant == 1 ? 0 : b->n_main;
+	int e = vgsdf_launch_tiles(ctx->variant >= 100 ? ctx->variant : 0, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_out,
+	                           ctx->stream);
+	if (e == 0)
+		e = vgsdf_launch_tiles(1, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
+		                       b->d_ey, b->d_out, ctx->stream);
 	if (e != 0) {
 		ctx->err = std::string("vgsdf_batch_launch: ") + hipGetErrorString((hipError_t)e);
 		return VGSDF_E_HIP;
