@@ -65,6 +65,9 @@ int vg_name_to_id(const char *name, char *out, size_t cap);
 int vg_manager_block_counts(const vg_manager *m, const char *font_id, uint32_t counts[256]);
 
 int vg_manager_render_glyphs(vg_manager *m, vg_renderer *r, vg_write_cb cb, void *user);
+/* A rank's shard: only the listed block starts (multiples of 256) of one font id. */
+int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id, const uint32_t *starts, int n,
+                             vg_write_cb cb, void *user);
 int vg_manager_timings(const vg_manager *m, vg_timings *out);
 /* GlyphBlock::render for one block of one font -> PBF bytes; returns needed size */
 long vg_manager_render_block(vg_manager *m, vg_renderer *r, const char *font_id, uint32_t start, uint8_t *out,

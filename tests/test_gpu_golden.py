@@ -1,0 +1,101 @@
+"""GPU: the product against the committed golden fixtures only (no oracle at run time):
+per-glyph bitmap SHA-256, per-block PBF SHA-256, sample bitmaps, first 64 synthetic outlines,
+plus size-independent properties at the benchmark's full size."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_golden_cpu import golden_rows, set_paths
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    c = vg.SdfContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["fira", "noto_regular", "noto_all"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_every_glyph_bitmap_sha(vg, ctx, name, variant):
+    disp, paths = set_paths(name)
+    m = vg.FontManager(True)
+    fid = m.add_font_with_name(disp, paths)
+    hb = m.build_batch(fid)
+    ctx.set_variant(variant)
+    out = ctx.render_batch(hb.batch)
+    ctx.set_variant(0)
+    raster = [r for r in golden_rows(name) if int(r["bitmap_size"])]
+    assert len(raster) == hb.batch.n_glyphs
+    bad = [r["codepoint"] for g, r in enumerate(raster)
+           if hashlib.sha256(hb.batch.bitmap(out, g).tobytes()).hexdigest() != r["sha256"]]
+    assert not bad, f"{len(bad)} glyphs differ: {bad[:8]}"
+
+
+@pytest.mark.parametrize("name", ["fira", "noto_regular", "noto_all"])
+def test_every_block_pbf_sha(vg, name):
+    disp, paths = set_paths(name)
+    m = vg.FontManager(True)
+    fid = m.add_font_with_name(disp, paths)
+    w = vg.DummyWriter()
+    m.render_glyphs(w, vg.Renderer.new_precise(0))
+    want = json.loads((GOLDEN / "pbf_sha256.json").read_text())[name]
+    bad = [s for s, sha in want.items()
+           if hashlib.sha256(w.files[f"{fid}/{s}-{int(s) + 255}.pbf"]).hexdigest() != sha]
+    assert not bad, bad
+
+
+def test_sample_bitmaps(vg, ctx):
+    z = np.load(GOLDEN / "samples.npz")
+    keys = sorted(k[:-5] for k in z.files if k.endswith("_segs"))
+    batch = vg.make_batch((z[k + "_segs"], *(int(v) for v in z[k + "_rect"])) for k in keys)
+    out = ctx.render_batch(batch)
+    for g, k in enumerate(keys):
+        assert np.array_equal(batch.bitmap(out, g), z[k + "_bitmap"]), k
+
+
+def test_synthetic_first_64(vg, ctx):
+    from versatiles_glyphs_rs_amd import synthetic as S
+    want = np.load(GOLDEN / "synthetic64.npz")["bitmaps"]
+    out = ctx.render_batch(S.make_batch(0, 64)).reshape(64, S.H, S.W)
+    assert np.array_equal(out, want)
+
+
+def test_full_size_properties(vg, ctx):
+    """Properties that need no reference, at the benchmark's full batch (Noto Sans Regular):
+    the two kernel variants agree byte for byte; rendering is idempotent; glyph order inside a
+    batch does not matter; translating a glyph by whole pixels (segments and rect together)
+    leaves its bitmap unchanged (the raster only sees coordinates relative to the samples)."""
+    disp, paths = set_paths("noto_regular")
+    m = vg.FontManager(True)
+    hb = m.build_batch(m.add_font_with_name(disp, paths))
+    b = hb.batch
+    a0 = ctx.render_batch(b)
+    ctx.set_variant(1)
+    a1 = ctx.render_batch(b)
+    ctx.set_variant(0)
+    assert np.array_equal(a0, a1)
+    assert np.array_equal(ctx.render_batch(b), a0)
+    # reversed glyph order
+    n = b.n_glyphs
+    rev = vg.make_batch((np.stack([b.seg_sx[b.seg_off[g]:b.seg_off[g + 1]], b.seg_sy[b.seg_off[g]:b.seg_off[g + 1]],
+                                   b.seg_ex[b.seg_off[g]:b.seg_off[g + 1]], b.seg_ey[b.seg_off[g]:b.seg_off[g + 1]]], 1),
+                         int(b.x0[g]), int(b.y0[g]), int(b.w[g]), int(b.h[g])) for g in range(n - 1, -1, -1))
+    r = ctx.render_batch(rev)
+    for g in (0, 1, n // 2, n - 1):
+        assert np.array_equal(rev.bitmap(r, n - 1 - g), b.bitmap(a0, g))
+    # integer translation (exact in f64 for these magnitudes: coordinates are k/2^j with small k)
+    sh = vg.make_batch((np.stack([b.seg_sx[b.seg_off[g]:b.seg_off[g + 1]] + 64.0, b.seg_sy[b.seg_off[g]:b.seg_off[g + 1]] - 32.0,
+                                  b.seg_ex[b.seg_off[g]:b.seg_off[g + 1]] + 64.0, b.seg_ey[b.seg_off[g]:b.seg_off[g + 1]] - 32.0], 1),
+                        int(b.x0[g]) + 64, int(b.y0[g]) - 32, int(b.w[g]), int(b.h[g])) for g in range(0, n, 37))
+    s = ctx.render_batch(sh)
+    exact = 0
+    for i, g in enumerate(range(0, n, 37)):
+        exact += np.array_equal(sh.bitmap(s, i), b.bitmap(a0, g))
+    # translation by 64/32 px is exact only when no coordinate loses a low bit; nearly all do not
+    assert exact >= 0.9 * len(range(0, n, 37))

@@ -14,3 +14,4 @@ from .device import (  # noqa: F401
 from .host import (  # noqa: F401
     DummyWriter, FontManager, GlyphBatchHost, PbfGlyph, Renderer, name_to_id, pbf_encode,
 )
+from .dispatch import render_sharded, shard_blocks  # noqa: F401

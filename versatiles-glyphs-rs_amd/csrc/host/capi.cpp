@@ -116,6 +116,17 @@ int vg_manager_render_glyphs(vg_manager *m, vg_renderer *r, vg_write_cb cb, void
 		return fail(e.what());
 	}
 }
+int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id, const uint32_t *starts, int n,
+                             vg_write_cb cb, void *user)
+{
+	try {
+		CallbackWriter w(cb, user);
+		m->m.render_blocks(w, *r->r, font_id, std::vector<uint32_t>(starts, starts + n));
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
 int vg_manager_timings(const vg_manager *m, vg_timings *out)
 {
 	const vg::RenderTimings &t = m->m.last_timings();

@@ -219,13 +219,6 @@ bool FontManager::build_batch(const std::string &font_id, GlyphBatch &out, std::
 
 void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 {
-	struct Todo {
-		const std::string *name;
-		GlyphBlock block;
-	};
-	timings_ = RenderTimings{};
-	const double t_start = now_s();
-
 	// manager.rs:86-97: one task per (font, block); all 256 blocks per font
 	std::vector<Todo> tasks;
 	for (const auto &[name, font] : fonts_) {
@@ -233,6 +226,29 @@ void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 		for (GlyphBlock &b : font.get_blocks())
 			tasks.push_back(Todo{&name, std::move(b)});
 	}
+	run_tasks(tasks, writer, renderer);
+}
+
+void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const std::string &font_id,
+                                const std::vector<uint32_t> &block_starts)
+{
+	auto it = fonts_.find(font_id);
+	if (it == fonts_.end())
+		throw std::runtime_error("unknown font id " + font_id);
+	std::vector<GlyphBlock> blocks = it->second.get_blocks();
+	std::vector<Todo> tasks;
+	for (uint32_t start : block_starts) {
+		if (start % GLYPH_BLOCK_SIZE || start / GLYPH_BLOCK_SIZE >= blocks.size())
+			throw std::runtime_error("bad block start " + std::to_string(start));
+		tasks.push_back(Todo{&it->first, blocks[start / GLYPH_BLOCK_SIZE]});
+	}
+	run_tasks(tasks, writer, renderer);
+}
+
+void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer)
+{
+	timings_ = RenderTimings{};
+	const double t_start = now_s();
 
 	const unsigned workers = worker_count();
 	std::vector<TessScratch> scratch(workers);

@@ -101,6 +101,10 @@ public:
 	// them, blocks are PBF-encoded and handed to the writer in task order.  Throws
 	// std::runtime_error on failure (first error aborts, like try_for_each).
 	void render_glyphs(Writer &writer, const Renderer &renderer);
+	// Same, restricted to the given block start indices of one font (a rank's shard of the
+	// (font, block) task list; blocks are independent: manager.rs:86-97).
+	void render_blocks(Writer &writer, const Renderer &renderer, const std::string &font_id,
+	                   const std::vector<uint32_t> &block_starts);
 
 	// Host stage only: every rasterised glyph of one font, blocks in ascending order (the
 	// batch a bench/test keeps resident in HBM).
@@ -112,6 +116,11 @@ public:
 	void set_batch_blocks(unsigned n) { batch_blocks_ = n ? n : 1; }
 
 private:
+	struct Todo {
+		const std::string *name;
+		GlyphBlock block;
+	};
+	void run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
 	unsigned worker_count() const;
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
 	bool parallel_;

@@ -39,7 +39,7 @@ VGFONT_SYMBOLS = [
     "vg_last_error", "vg_renderer_new", "vg_renderer_free", "vg_manager_new", "vg_manager_free",
     "vg_manager_set_threads", "vg_manager_add_font_with_name", "vg_manager_add_font_data", "vg_manager_add_path",
     "vg_name_to_id", "vg_manager_block_counts", "vg_manager_render_glyphs", "vg_manager_timings",
-    "vg_manager_render_block", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
+    "vg_manager_render_block", "vg_manager_render_blocks", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
     "vg_glyph_batch_free", "vg_pbf_encode",
 ]
 
@@ -65,6 +65,7 @@ def _L():
         L.vg_name_to_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.vg_manager_block_counts.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32)]
         L.vg_manager_render_glyphs.argtypes = [vp, vp, WRITE_CB, vp]
+        L.vg_manager_render_blocks.argtypes = [vp, vp, C.c_char_p, C.POINTER(C.c_uint32), C.c_int, WRITE_CB, vp]
         L.vg_manager_timings.argtypes = [vp, C.POINTER(Timings)]
         L.vg_manager_render_block.restype = C.c_long
         L.vg_manager_render_block.argtypes = [vp, vp, C.c_char_p, C.c_uint32, vp, C.c_size_t]
@@ -208,9 +209,10 @@ class FontManager:
             raise KeyError(_err())
         return out
 
-    def render_glyphs(self, writer, renderer: Renderer):
+    def render_glyphs(self, writer, renderer: Renderer, font_id: str = None, block_starts=None):
         """FontManager::render_glyphs(&mut writer, &renderer).  `writer` needs
-        write_directory(path) and write_file(path, bytes)."""
+        write_directory(path) and write_file(path, bytes).  With font_id + block_starts only
+        that shard of the (font, block) task list is rendered."""
         errors = []
 
         def cb(_user, path, data, n, is_dir):
@@ -225,7 +227,11 @@ class FontManager:
                 return 1
 
         ccb = WRITE_CB(cb)
-        rc = _L().vg_manager_render_glyphs(self._h, renderer._h, ccb, None)
+        if block_starts is None:
+            rc = _L().vg_manager_render_glyphs(self._h, renderer._h, ccb, None)
+        else:
+            arr = (C.c_uint32 * max(len(block_starts), 1))(*[int(b) for b in block_starts])
+            rc = _L().vg_manager_render_blocks(self._h, renderer._h, font_id.encode(), arr, len(block_starts), ccb, None)
         if errors:
             raise errors[0]
         if rc != 0:
