@@ -3,6 +3,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <stdexcept>
 #include <thread>
@@ -194,8 +195,13 @@ unsigned FontManager::worker_count() const
 		return 1;
 	if (threads_)
 		return threads_;
+	// default: the machine's threads, capped at one GPU's CPU share of an 8-GPU node (16);
+	// VG_THREADS or set_threads() override
+	if (const char *e = std::getenv("VG_THREADS"))
+		if (int v = std::atoi(e); v > 0)
+			return (unsigned)v;
 	const unsigned hc = std::thread::hardware_concurrency();
-	return hc ? hc : 1;
+	return hc ? std::min(hc, 16u) : 1;
 }
 
 bool FontManager::build_batch(const std::string &font_id, GlyphBatch &out, std::string *err) const

@@ -332,8 +332,18 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 		const uint32_t cnt4 = cnt_f & ~3u;
 		const float4 *s_len4 = reinterpret_cast<const float4 *>(s_len);
 		for (uint32_t i = 0; i < cnt4; i += 4) {
-			const float4 a0 = s_f[i], a1 = s_f[i + 1], a2 = s_f[i + 2], a3 = s_f[i + 3];
-			const float4 l = s_len4[i >> 2];
+			float4 a0 = s_f[i], a1, a2, a3, l;
+			if (ABL & 32) { // timing only: one LDS read per 4 segments
+				a1 = make_float4(a0.y, a0.x, a0.w, a0.z);
+				a2 = make_float4(a0.x + 1.0f, a0.y, a0.z, a0.w);
+				a3 = make_float4(a0.x, a0.y + 1.0f, a0.w, a0.z);
+				l = make_float4(a0.z, a0.w, a0.z, a0.w);
+			} else {
+				a1 = s_f[i + 1];
+				a2 = s_f[i + 2];
+				a3 = s_f[i + 3];
+				l = s_len4[i >> 2];
+			}
 			consider(a0, l.x, i);
 			consider(a1, l.y, i + 1);
 			consider(a2, l.z, i + 2);
@@ -420,6 +430,7 @@ extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, c
 		case 4: VG_LAUNCH_FILTERED(4); break;
 		case 6: VG_LAUNCH_FILTERED(6); break;
 		case 8: VG_LAUNCH_FILTERED(8); break;
+		case 36: VG_LAUNCH_FILTERED(36); break;
 		case 16: VG_LAUNCH_FILTERED(16); break;
 		case 23: VG_LAUNCH_FILTERED(23); break;
 		case 22: VG_LAUNCH_FILTERED(22); break;
