@@ -58,6 +58,17 @@ def workload_files(name):
     return disp, paths
 
 
+def traffic_bytes(workload, variant):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950
+    correction applied) in a separate profiling run: profiles/traffic.json, written by
+    tools/summarize_profile.py.  None when this (workload, variant) has not been profiled."""
+    try:
+        d = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        return d[f"{workload}:{variant}"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,8 +180,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": alg_gbs / HBM_PEAK_GBS,
-            "traffic": None,
-            "kernel": "sdf_tiles (dominant and only kernel of a step)",
+            "traffic": traffic_bytes(args.workload, args.variant),
+            "kernel": "sdf_tiles_filtered (dominant and only kernel of a step)" if args.variant == 0 else "sdf_tiles",
             "kernel_ms_avg": kernel_s * 1e3,
             "alg_bytes_per_launch": st["alg_bytes"],
             "note": "the path is FP64-VALU bound by construction (~250 flop/byte); see roofline_valu",

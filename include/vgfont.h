@@ -40,7 +40,7 @@ typedef struct {
 
 /* phases of the last vg_manager_render_glyphs call */
 typedef struct {
-	double tessellate_s, device_s, encode_s, write_s, total_s;
+	double tessellate_s, pack_s, device_s, encode_s, write_s, total_s;
 	uint64_t blocks, glyphs, rasters, pixels, segments, pbf_bytes;
 } vg_timings;
 
@@ -81,7 +81,7 @@ int vg_render_glyph(vg_renderer *r, const vg_manager *m, const char *font_id, in
 /* Host stage only (cmap -> outline -> flatten -> scale/shift -> bbox) for every glyph of a
  * font id: the SoA batch to hand to vgsdf_batch_upload.  Pointers in *view stay valid
  * until vg_glyph_batch_free.  ids[i] = code point of rasterised glyph i. */
-vg_glyph_batch *vg_manager_build_batch(const vg_manager *m, const char *font_id);
+vg_glyph_batch *vg_manager_build_batch(vg_manager *m, const char *font_id);
 int vg_glyph_batch_view(const vg_glyph_batch *b, vgsdf_batch *view, const uint32_t **ids, uint32_t *n_jobs);
 void vg_glyph_batch_free(vg_glyph_batch *b);
 

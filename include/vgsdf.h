@@ -81,6 +81,12 @@ int vgsdf_create(int device_ordinal, vgsdf_ctx **out);
 void vgsdf_destroy(vgsdf_ctx *ctx);
 const char *vgsdf_last_error(const vgsdf_ctx *ctx); /* ctx may be NULL: last create error */
 
+/* Page-locked host memory (hipHostMalloc).  Batch arrays / output buffers allocated with it
+ * are DMA'd directly by vgsdf_render_batch / vgsdf_batch_upload / _download (no staging
+ * copy).  Returns NULL when HIP is unavailable.  Optional: plain memory works too. */
+void *vgsdf_host_alloc(size_t bytes);
+void vgsdf_host_free(void *p);
+
 /* Synchronous whole-batch render: H2D, kernel, D2H; out_bitmaps is host memory of
  * out_off[n_glyphs] bytes. */
 int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitmaps);

@@ -1,0 +1,21 @@
+"""end-to-end (fonts -> PBF bytes) timing of the host pipeline + GPU (development aid)"""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from conftest import load_product, NOTO, noto_files
+vg = load_product()
+which = sys.argv[1] if len(sys.argv) > 1 else "noto_regular"
+paths = [NOTO] if which == "noto_regular" else noto_files()
+r = vg.Renderer.new_precise(0) if vg.device_count() else vg.Renderer.new_dummy()
+for th in (1, 4, 8, 16, 32):
+    m = vg.FontManager(True); m.set_threads(th, 0)
+    fid = m.add_font_with_name("Noto Sans Regular", paths)
+    best = None
+    for i in range(4):
+        w = vg.DummyWriter(); t = time.perf_counter(); m.render_glyphs(w, r); dt = time.perf_counter() - t
+        if i == 0: cold = dt
+        best = dt if best is None else min(best, dt)
+    tm = m.timings()
+    print(f"{which} threads {th}: cold {cold*1e3:.1f} ms, best {best*1e3:.1f} ms -> {tm['glyphs']/best:.0f} glyphs/s | " +
+          " ".join(f"{k[:-2]}={v*1e3:.2f}" for k, v in tm.items() if k.endswith('_s')), flush=True)

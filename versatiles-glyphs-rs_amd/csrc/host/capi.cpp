@@ -22,8 +22,9 @@ struct vg_manager {
 	explicit vg_manager(bool p) : m(p) {}
 };
 struct vg_glyph_batch {
-	vg::GlyphBatch b;
+	vg::PackedBatch b;
 	std::vector<uint32_t> ids;
+	uint32_t n_jobs = 0;
 };
 
 namespace {
@@ -130,7 +131,7 @@ int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id,
 int vg_manager_timings(const vg_manager *m, vg_timings *out)
 {
 	const vg::RenderTimings &t = m->m.last_timings();
-	*out = vg_timings{t.tessellate_s, t.device_s, t.encode_s, t.write_s, t.total_s, t.blocks,
+	*out = vg_timings{t.tessellate_s, t.pack_s, t.device_s, t.encode_s, t.write_s, t.total_s, t.blocks,
 	                  t.glyphs,       t.rasters,  t.pixels,   t.segments, t.pbf_bytes};
 	return 0;
 }
@@ -185,18 +186,16 @@ int vg_render_glyph(vg_renderer *r, const vg_manager *m, const char *font_id, in
 	}
 }
 
-vg_glyph_batch *vg_manager_build_batch(const vg_manager *m, const char *font_id)
+vg_glyph_batch *vg_manager_build_batch(vg_manager *m, const char *font_id)
 {
 	try {
 		auto *b = new vg_glyph_batch();
 		std::string err;
-		if (!m->m.build_batch(font_id, b->b, &err)) {
+		if (!m->m.build_batch(font_id, b->b, b->ids, b->n_jobs, &err)) {
 			delete b;
 			g_err = err;
 			return nullptr;
 		}
-		for (uint32_t j : b->b.raster_job)
-			b->ids.push_back(b->b.jobs[j].id);
 		return b;
 	} catch (const std::exception &e) {
 		g_err = e.what();
@@ -209,7 +208,7 @@ int vg_glyph_batch_view(const vg_glyph_batch *b, vgsdf_batch *view, const uint32
 	if (ids)
 		*ids = b->ids.data();
 	if (n_jobs)
-		*n_jobs = (uint32_t)b->b.jobs.size();
+		*n_jobs = b->n_jobs;
 	return 0;
 }
 void vg_glyph_batch_free(vg_glyph_batch *b) { delete b; }

@@ -2,6 +2,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -35,41 +36,6 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string *
 		return false;
 	}
 	return true;
-}
-
-// runs fn(i) for i in [0,n) on `workers` threads (dynamic scheduling); rethrows the first error
-template <class F> void parallel_for(size_t n, unsigned workers, F &&fn)
-{
-	if (workers <= 1 || n <= 1) {
-		for (size_t i = 0; i < n; i++)
-			fn(i, 0u);
-		return;
-	}
-	std::atomic<size_t> next{0};
-	std::atomic<bool> failed{false};
-	std::string first_error;
-	std::mutex err_mu;
-	std::vector<std::thread> pool;
-	const unsigned nt = (unsigned)std::min<size_t>(workers, n);
-	for (unsigned t = 0; t < nt; t++)
-		pool.emplace_back([&, t] {
-			for (;;) {
-				const size_t i = next.fetch_add(1);
-				if (i >= n || failed.load())
-					return;
-				try {
-					fn(i, t);
-				} catch (const std::exception &e) {
-					std::lock_guard<std::mutex> l(err_mu);
-					if (!failed.exchange(true))
-						first_error = e.what();
-				}
-			}
-		});
-	for (auto &th : pool)
-		th.join();
-	if (failed.load())
-		throw std::runtime_error(first_error);
 }
 
 } // namespace
@@ -114,9 +80,9 @@ std::string GlyphBlock::range() const
 	return std::to_string(start_index) + "-" + std::to_string(start_index + GLYPH_BLOCK_SIZE - 1);
 }
 
-void GlyphBlock::prepare(TessScratch &scratch, GlyphBatch &batch) const
+void GlyphBlock::prepare(TessScratch &scratch, GlyphBatch &batch, uint32_t ci0, uint32_t ci1) const
 {
-	for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+	for (uint32_t ci = ci0; ci < ci1 && ci < GLYPH_BLOCK_SIZE; ci++)
 		if (const FontFileEntry *f = glyphs[ci])
 			Renderer::prepare(f->face(), start_index + ci, scratch, batch);
 }
@@ -204,7 +170,99 @@ unsigned FontManager::worker_count() const
 	return hc ? std::min(hc, 16u) : 1;
 }
 
-bool FontManager::build_batch(const std::string &font_id, GlyphBatch &out, std::string *err) const
+ThreadPool &FontManager::pool()
+{
+	const unsigned want = worker_count();
+	if (!pool_ || pool_->size() != want) {
+		pool_.reset(new ThreadPool(want));
+		workers_.clear();
+		workers_.resize(want);
+	}
+	return *pool_;
+}
+
+void FontManager::tessellate_and_pack(const std::vector<Todo> &tasks, size_t t0, size_t t1,
+                                      std::vector<Slice> &slices, PackedBatch &out)
+{
+	constexpr uint32_t kSlice = 64; // code points per unit of host work
+	ThreadPool &tp = pool();
+	slices.clear();
+	for (size_t t = t0; t < t1; t++) {
+		if (tasks[t].block.is_empty())
+			continue;
+		for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += kSlice) {
+			Slice s;
+			s.task = (uint32_t)t;
+			s.ci0 = c;
+			s.ci1 = c + kSlice;
+			slices.push_back(s);
+		}
+	}
+	for (Worker &w : workers_)
+		w.local.clear();
+	const double t_begin = now_s();
+
+	// T: tessellate every slice into its worker's local batch (capacity is retained run to run)
+	tp.run(slices.size(), [&](size_t i, unsigned wid) {
+		Slice &s = slices[i];
+		Worker &w = workers_[wid];
+		s.worker = wid;
+		s.job0 = (uint32_t)w.local.jobs.size();
+		s.raster0 = (uint32_t)w.local.n_raster();
+		tasks[s.task].block.prepare(w.scratch, w.local, s.ci0, s.ci1);
+		s.job1 = (uint32_t)w.local.jobs.size();
+		s.raster1 = (uint32_t)w.local.n_raster();
+	});
+
+	const double t_tess_done = now_s();
+	// P: positions in the packed batch, in task order (deterministic: ascending id per font)
+	uint32_t rasters = 0;
+	uint64_t segs = 0, pixels = 0;
+	for (Slice &s : slices) {
+		const GlyphBatch &l = workers_[s.worker].local;
+		s.g_raster = rasters;
+		s.g_seg = segs;
+		s.g_out = pixels;
+		rasters += s.raster1 - s.raster0;
+		segs += l.seg_off[s.raster1] - l.seg_off[s.raster0];
+		pixels += l.out_off[s.raster1] - l.out_off[s.raster0];
+	}
+	if (segs > 0xFFFFFFFFull)
+		throw std::runtime_error("batch exceeds 2^32 segments; lower set_batch_blocks()");
+	out.reserve(rasters, segs, pixels);
+	out.n_raster = rasters;
+	out.n_seg = segs;
+	out.out_bytes = pixels;
+
+	// C: copy the slices into the page-locked SoA arrays
+	tp.run(slices.size(), [&](size_t i, unsigned) {
+		const Slice &s = slices[i];
+		const GlyphBatch &l = workers_[s.worker].local;
+		const uint32_t ls0 = l.seg_off[s.raster0];
+		const size_t n = l.seg_off[s.raster1] - ls0;
+		if (n) {
+			std::memcpy(out.sx.data() + s.g_seg, l.sx.data() + ls0, n * sizeof(double));
+			std::memcpy(out.sy.data() + s.g_seg, l.sy.data() + ls0, n * sizeof(double));
+			std::memcpy(out.ex.data() + s.g_seg, l.ex.data() + ls0, n * sizeof(double));
+			std::memcpy(out.ey.data() + s.g_seg, l.ey.data() + ls0, n * sizeof(double));
+		}
+		const uint64_t lo0 = l.out_off[s.raster0];
+		for (uint32_t r = s.raster0; r < s.raster1; r++) {
+			const uint32_t g = s.g_raster + (r - s.raster0);
+			out.x0[g] = l.x0[r];
+			out.y0[g] = l.y0[r];
+			out.w[g] = l.w[r];
+			out.h[g] = l.h[r];
+			out.seg_off[g + 1] = (uint32_t)(s.g_seg + (l.seg_off[r + 1] - ls0));
+			out.out_off[g + 1] = s.g_out + (l.out_off[r + 1] - lo0);
+		}
+	});
+	timings_.tessellate_s += t_tess_done - t_begin;
+	timings_.pack_s += now_s() - t_tess_done;
+}
+
+bool FontManager::build_batch(const std::string &font_id, PackedBatch &out, std::vector<uint32_t> &ids,
+                              uint32_t &n_jobs, std::string *err)
 {
 	auto it = fonts_.find(font_id);
 	if (it == fonts_.end()) {
@@ -212,14 +270,19 @@ bool FontManager::build_batch(const std::string &font_id, GlyphBatch &out, std::
 			*err = "unknown font id " + font_id;
 		return false;
 	}
-	const std::vector<GlyphBlock> blocks = it->second.get_blocks();
-	std::vector<GlyphBatch> parts(blocks.size());
-	const unsigned workers = worker_count();
-	std::vector<TessScratch> scratch(workers);
-	parallel_for(blocks.size(), workers, [&](size_t i, unsigned t) { blocks[i].prepare(scratch[t], parts[i]); });
-	out.clear();
-	for (const GlyphBatch &p : parts)
-		out.append(p);
+	std::vector<Todo> tasks;
+	for (GlyphBlock &b : it->second.get_blocks())
+		tasks.push_back(Todo{&it->first, std::move(b)});
+	std::vector<Slice> slices;
+	tessellate_and_pack(tasks, 0, tasks.size(), slices, out);
+	ids.assign(out.n_raster, 0);
+	n_jobs = 0;
+	for (const Slice &s : slices) {
+		const GlyphBatch &l = workers_[s.worker].local;
+		n_jobs += s.job1 - s.job0;
+		for (uint32_t r = s.raster0; r < s.raster1; r++)
+			ids[s.g_raster + (r - s.raster0)] = l.jobs[l.raster_job[r]].id;
+	}
 	return true;
 }
 
@@ -255,48 +318,51 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 {
 	timings_ = RenderTimings{};
 	const double t_start = now_s();
-
-	const unsigned workers = worker_count();
-	std::vector<TessScratch> scratch(workers);
-	std::vector<uint8_t> pixels;
+	ThreadPool &tp = pool();
+	std::vector<Slice> slices;
 
 	// GPU batch dispatcher (replaces manager.rs:104-121): groups of `batch_blocks_` tasks are
-	// tessellated on host threads, rendered with one device submission, then encoded + written.
+	// tessellated on the pool, packed into page-locked SoA arrays, rendered with ONE device
+	// submission, then PBF-encoded on the pool and written in task order.
 	for (size_t g0 = 0; g0 < tasks.size(); g0 += batch_blocks_) {
 		const size_t g1 = std::min(tasks.size(), g0 + (size_t)batch_blocks_);
 		const size_t nb = g1 - g0;
 
-		double t0 = now_s();
-		std::vector<GlyphBatch> parts(nb);
-		parallel_for(nb, workers, [&](size_t i, unsigned t) { tasks[g0 + i].block.prepare(scratch[t], parts[i]); });
-		GlyphBatch batch;
-		std::vector<size_t> first_raster(nb + 1, 0);
-		for (size_t i = 0; i < nb; i++) {
-			first_raster[i] = batch.n_raster();
-			batch.append(parts[i]);
-		}
-		first_raster[nb] = batch.n_raster();
-		double t1 = now_s();
-		timings_.tessellate_s += t1 - t0;
+		tessellate_and_pack(tasks, g0, g1, slices, packed_);
+		const double t1 = now_s();
 
-		pixels.resize((size_t)batch.out_bytes());
-		renderer.render_batch(batch, pixels.data());
-		double t2 = now_s();
+		renderer.render_packed(packed_);
+		const double t2 = now_s();
 		timings_.device_s += t2 - t1;
 
+		// slices of a task are contiguous and in code point order
+		std::vector<std::pair<size_t, size_t>> span(nb, {0, 0});
+		for (size_t i = 0; i < slices.size(); i++) {
+			auto &sp = span[slices[i].task - g0];
+			if (sp.second == 0)
+				sp.first = i;
+			sp.second = i + 1;
+		}
 		std::vector<std::vector<uint8_t>> encoded(nb);
-		parallel_for(nb, workers, [&](size_t i, unsigned) {
-			const GlyphBatch &p = parts[i];
+		tp.run(nb, [&](size_t i, unsigned) {
 			std::vector<PbfGlyphRef> refs;
-			refs.reserve(p.jobs.size());
-			size_t r = first_raster[i];
-			for (const GlyphJob &j : p.jobs) {
-				const uint8_t *bm = j.has_raster ? pixels.data() + batch.out_off[r++] : nullptr;
-				refs.push_back(j.to_pbf(bm));
+			for (size_t k = span[i].first; k < span[i].second; k++) {
+				const Slice &s = slices[k];
+				const GlyphBatch &l = workers_[s.worker].local;
+				uint32_t r = s.raster0;
+				for (uint32_t j = s.job0; j < s.job1; j++) {
+					const GlyphJob &job = l.jobs[j];
+					const uint8_t *bm = nullptr;
+					if (job.has_raster) {
+						bm = packed_.out.data() + packed_.out_off[s.g_raster + (r - s.raster0)];
+						r++;
+					}
+					refs.push_back(job.to_pbf(bm));
+				}
 			}
 			encoded[i] = PbfGlyphs::encode(*tasks[g0 + i].name, tasks[g0 + i].block.range(), std::move(refs));
 		});
-		double t3 = now_s();
+		const double t3 = now_s();
 		timings_.encode_s += t3 - t2;
 
 		for (size_t i = 0; i < nb; i++) {
@@ -306,10 +372,11 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 		timings_.write_s += now_s() - t3;
 
 		timings_.blocks += nb;
-		timings_.glyphs += batch.jobs.size();
-		timings_.rasters += batch.n_raster();
-		timings_.pixels += batch.out_bytes();
-		timings_.segments += batch.seg_off.back();
+		for (const Slice &s : slices)
+			timings_.glyphs += s.job1 - s.job0;
+		timings_.rasters += packed_.n_raster;
+		timings_.pixels += packed_.out_bytes;
+		timings_.segments += packed_.n_seg;
 	}
 	timings_.total_s = now_s() - t_start;
 }

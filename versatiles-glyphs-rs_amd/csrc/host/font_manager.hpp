@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "renderer.hpp"
+#include "thread_pool.hpp"
 
 namespace vg {
 
@@ -64,8 +65,9 @@ struct GlyphBlock {
 	std::string range() const; // glyph_block.rs:53-59
 	std::string filename() const { return range() + ".pbf"; } // :85-87
 
-	// Host half of GlyphBlock::render (glyph_block.rs:72-77), glyphs in ascending id.
-	void prepare(TessScratch &scratch, GlyphBatch &batch) const;
+	// Host half of GlyphBlock::render (glyph_block.rs:72-77), glyphs in ascending id;
+	// [ci0, ci1) restricts it to a sub-range of the block's 256 code points.
+	void prepare(TessScratch &scratch, GlyphBatch &batch, uint32_t ci0 = 0, uint32_t ci1 = GLYPH_BLOCK_SIZE) const;
 	// glyph_block.rs:69-80 complete (one block through the renderer)
 	std::vector<uint8_t> render(const std::string &font_name, const Renderer &renderer) const;
 };
@@ -83,7 +85,7 @@ private:
 };
 
 struct RenderTimings {
-	double tessellate_s = 0, device_s = 0, encode_s = 0, write_s = 0, total_s = 0;
+	double tessellate_s = 0, pack_s = 0, device_s = 0, encode_s = 0, write_s = 0, total_s = 0;
 	uint64_t blocks = 0, glyphs = 0, rasters = 0, pixels = 0, segments = 0, pbf_bytes = 0;
 };
 
@@ -107,8 +109,9 @@ public:
 	                   const std::vector<uint32_t> &block_starts);
 
 	// Host stage only: every rasterised glyph of one font, blocks in ascending order (the
-	// batch a bench/test keeps resident in HBM).
-	bool build_batch(const std::string &font_id, GlyphBatch &out, std::string *err) const;
+	// batch a bench/test keeps resident in HBM).  ids[i] = code point of rasterised glyph i.
+	bool build_batch(const std::string &font_id, PackedBatch &out, std::vector<uint32_t> &ids, uint32_t &n_jobs,
+	                 std::string *err);
 
 	const std::map<std::string, FontWrapper> &fonts() const { return fonts_; }
 	const RenderTimings &last_timings() const { return timings_; }
@@ -120,8 +123,30 @@ private:
 		const std::string *name;
 		GlyphBlock block;
 	};
+	// One unit of host work: a 64-code-point slice of a task's block, tessellated into the
+	// worker's local batch; the ranges say where.
+	struct alignas(64) Slice {
+		uint32_t task = 0, ci0 = 0, ci1 = 0;
+		unsigned worker = 0;
+		uint32_t job0 = 0, job1 = 0;       // jobs [job0, job1) of the worker-local batch
+		uint32_t raster0 = 0, raster1 = 0; // rasterised glyphs [raster0, raster1) of it
+		uint32_t g_raster = 0;             // first raster index in the packed batch
+		uint64_t g_seg = 0, g_out = 0;     // first segment / output byte in the packed batch
+	};
+	struct alignas(128) Worker { // own cache lines: the vector headers inside are written per glyph
+		TessScratch scratch;
+		GlyphBatch local;
+		char pad[128];
+	};
 	void run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
+	// tessellate tasks [t0, t1) on the pool and pack them (task order, ascending id) into `out`
+	void tessellate_and_pack(const std::vector<Todo> &tasks, size_t t0, size_t t1, std::vector<Slice> &slices,
+	                         PackedBatch &out);
+	ThreadPool &pool();
 	unsigned worker_count() const;
+	std::unique_ptr<ThreadPool> pool_;
+	std::vector<Worker> workers_;
+	PackedBatch packed_;
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
 	bool parallel_;
 	unsigned threads_ = 0;       // 0 = hardware_concurrency

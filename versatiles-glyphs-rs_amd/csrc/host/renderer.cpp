@@ -85,6 +85,40 @@ void GlyphBatch::append(const GlyphBatch &o)
 		out_off.push_back(out_base + o.out_off[i]);
 }
 
+void PackedBatch::reserve(uint32_t rasters, uint64_t segs, uint64_t pixels)
+{
+	seg_off.ensure((size_t)rasters + 1);
+	out_off.ensure((size_t)rasters + 1);
+	x0.ensure(rasters);
+	y0.ensure(rasters);
+	w.ensure(rasters);
+	h.ensure(rasters);
+	sx.ensure(segs);
+	sy.ensure(segs);
+	ex.ensure(segs);
+	ey.ensure(segs);
+	out.ensure(pixels);
+	seg_off[0] = 0;
+	out_off[0] = 0;
+}
+
+vgsdf_batch PackedBatch::view() const
+{
+	vgsdf_batch b;
+	b.n_glyphs = n_raster;
+	b.seg_off = seg_off.data();
+	b.seg_sx = sx.data();
+	b.seg_sy = sy.data();
+	b.seg_ex = ex.data();
+	b.seg_ey = ey.data();
+	b.x0 = x0.data();
+	b.y0 = y0.data();
+	b.w = w.data();
+	b.h = h.data();
+	b.out_off = out_off.data();
+	return b;
+}
+
 std::shared_ptr<Renderer> Renderer::create(bool dummy, int device, std::string *err)
 {
 	return dummy ? new_dummy() : new_precise(device, err);
@@ -198,6 +232,20 @@ void Renderer::render_batch(const GlyphBatch &batch, uint8_t *out) const
 	std::lock_guard<std::mutex> lock(mu_);
 	const vgsdf_batch v = batch.view();
 	if (vgsdf_render_batch(ctx_, &v, out) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_render_batch: ") + vgsdf_last_error(ctx_));
+}
+
+void Renderer::render_packed(PackedBatch &batch) const
+{
+	if (batch.n_raster == 0)
+		return;
+	if (mode_ == Mode::Dummy) { // renderer_dummy.rs:3-5
+		std::memset(batch.out.data(), 0, (size_t)batch.out_bytes);
+		return;
+	}
+	std::lock_guard<std::mutex> lock(mu_);
+	const vgsdf_batch v = batch.view();
+	if (vgsdf_render_batch(ctx_, &v, batch.out.data()) != VGSDF_OK)
 		throw std::runtime_error(std::string("vgsdf_render_batch: ") + vgsdf_last_error(ctx_));
 }
 

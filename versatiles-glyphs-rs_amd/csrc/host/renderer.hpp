@@ -13,7 +13,9 @@
 // (prepare -> GlyphBatch -> render_batch) that FontManager::render_glyphs drives.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <optional>
 #include <string>
@@ -75,6 +77,71 @@ struct GlyphBatch {
 	void append(const GlyphBatch &o);
 };
 
+// Grow-only host array; page-locked (vgsdf_host_alloc) when HIP is available so the device
+// layer can DMA it without a staging copy, plain malloc otherwise (dummy renderer on CPU).
+template <class T> class HostBuffer {
+public:
+	explicit HostBuffer(bool want_pinned = false) : want_pinned_(want_pinned) {}
+	HostBuffer(const HostBuffer &) = delete;
+	HostBuffer &operator=(const HostBuffer &) = delete;
+	~HostBuffer() { release(); }
+	// contents are NOT preserved across a growth
+	void ensure(size_t n)
+	{
+		if (n <= cap_)
+			return;
+		release();
+		const size_t want = n + n / 4 + 64;
+		if (want_pinned_) {
+			p_ = static_cast<T *>(vgsdf_host_alloc(want * sizeof(T)));
+			pinned_ = p_ != nullptr;
+		}
+		if (!p_) {
+			p_ = static_cast<T *>(std::malloc(want * sizeof(T)));
+			if (!p_)
+				throw std::bad_alloc();
+		}
+		cap_ = want;
+	}
+	T *data() { return p_; }
+	const T *data() const { return p_; }
+	T &operator[](size_t i) { return p_[i]; }
+	const T &operator[](size_t i) const { return p_[i]; }
+
+private:
+	void release()
+	{
+		if (p_) {
+			if (pinned_)
+				vgsdf_host_free(p_);
+			else
+				std::free(p_);
+		}
+		p_ = nullptr;
+		cap_ = 0;
+		pinned_ = false;
+	}
+	T *p_ = nullptr;
+	size_t cap_ = 0;
+	bool want_pinned_, pinned_ = false;
+};
+
+// The batch as the device boundary wants it (include/vgsdf.h), in reusable buffers; the big
+// arrays (segments, output pixels) are page-locked.
+struct PackedBatch {
+	HostBuffer<uint32_t> seg_off;
+	HostBuffer<double> sx{true}, sy{true}, ex{true}, ey{true};
+	HostBuffer<int32_t> x0, y0;
+	HostBuffer<uint32_t> w, h;
+	HostBuffer<uint64_t> out_off;
+	HostBuffer<uint8_t> out{true};
+	uint32_t n_raster = 0;
+	uint64_t n_seg = 0, out_bytes = 0;
+
+	void reserve(uint32_t rasters, uint64_t segs, uint64_t pixels);
+	vgsdf_batch view() const;
+};
+
 // Per-thread scratch so tessellation allocates nothing in steady state.
 struct TessScratch {
 	RingBuilder builder;
@@ -101,6 +168,8 @@ public:
 	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one
 	// vgsdf_render_batch call; Dummy: zeros (renderer_dummy.rs).  Throws std::runtime_error.
 	void render_batch(const GlyphBatch &batch, uint8_t *out) const;
+	// Same for a packed (page-locked) batch; pixels land in batch.out.
+	void render_packed(PackedBatch &batch) const;
 
 	// renderer.rs:103 — per-glyph API kept for drop-in parity (a batch of one).
 	std::optional<PbfGlyph> render_glyph(const Face &face, uint32_t index) const;

@@ -18,6 +18,20 @@ thread_local std::string g_create_error;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// true when p is page-locked host memory known to HIP (hipHostMalloc / vgsdf_host_alloc):
+// such arrays are DMA'd straight from/to the caller without a staging copy
+inline bool is_pinned(const void *p)
+{
+	if (!p)
+		return false;
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+		(void)hipGetLastError(); // plain malloc memory: clear the sticky error
+		return false;
+	}
+	return a.type == hipMemoryTypeHost;
+}
+
 } // namespace
 
 struct vgsdf_ctx {
@@ -26,6 +40,9 @@ struct vgsdf_ctx {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int variant = 0;
 	std::string err;
+	// grow-only scratch of vgsdf_render_batch: no hipMalloc / hipHostMalloc in steady state
+	void *d_scratch = nullptr, *h_scratch = nullptr;
+	size_t d_scratch_bytes = 0, h_scratch_bytes = 0;
 };
 
 struct vgsdf_dbatch {
@@ -40,6 +57,7 @@ struct vgsdf_dbatch {
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
 	uint32_t n_main = 0; // tiles [0, n_main) go to the filtered kernel, the rest to brute force
+	bool borrowed = false; // arena + staging belong to the context (vgsdf_render_batch)
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -110,6 +128,10 @@ void vgsdf_destroy(vgsdf_ctx *ctx)
 		(void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1)
 		(void)hipEventDestroy(ctx->ev1);
+	if (ctx->d_scratch)
+		(void)hipFree(ctx->d_scratch);
+	if (ctx->h_scratch)
+		(void)hipHostFree(ctx->h_scratch);
 	delete ctx;
 }
 
@@ -142,15 +164,17 @@ int vgsdf_batch_free(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_OK;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
-	if (b->d_arena)
-		(void)hipFree(b->d_arena);
-	if (b->h_stage)
-		(void)hipHostFree(b->h_stage);
+	if (!b->borrowed) {
+		if (b->d_arena)
+			(void)hipFree(b->d_arena);
+		if (b->h_stage)
+			(void)hipHostFree(b->h_stage);
+	}
 	delete b;
 	return VGSDF_OK;
 }
 
-int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out)
+static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out, bool use_ctx_scratch)
 {
 	if (!ctx)
 		return VGSDF_E_ARG;
@@ -223,18 +247,57 @@ int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	b->arena_bytes = off ? off : A;
 
 	(void)hipSetDevice(ctx->device);
-	hipError_t e = hipMalloc(&b->d_arena, b->arena_bytes);
-	if (e != hipSuccess) {
-		ctx->err = std::string("vgsdf_batch_upload: hipMalloc: ") + hipGetErrorString(e);
-		delete b;
-		return VGSDF_E_OOM;
-	}
-	if (b->input_bytes) {
-		e = hipHostMalloc(&b->h_stage, b->input_bytes, hipHostMallocDefault);
+	hipError_t e = hipSuccess;
+	// segment arrays already page-locked: DMA them directly, stage only descriptors + tiles
+	const bool direct = n_seg && is_pinned(in->seg_sx) && is_pinned(in->seg_sy) && is_pinned(in->seg_ex) &&
+	                    is_pinned(in->seg_ey);
+	const size_t stage_bytes = direct ? off_sx : b->input_bytes;
+	if (use_ctx_scratch) {
+		b->borrowed = true;
+		if (ctx->d_scratch_bytes < b->arena_bytes) {
+			(void)hipStreamSynchronize(ctx->stream);
+			if (ctx->d_scratch)
+				(void)hipFree(ctx->d_scratch);
+			ctx->d_scratch = nullptr;
+			ctx->d_scratch_bytes = 0;
+			const size_t want = b->arena_bytes + b->arena_bytes / 4;
+			if ((e = hipMalloc(&ctx->d_scratch, want)) != hipSuccess) {
+				ctx->err = std::string("vgsdf_render_batch: hipMalloc: ") + hipGetErrorString(e);
+				delete b;
+				return VGSDF_E_OOM;
+			}
+			ctx->d_scratch_bytes = want;
+		}
+		if (ctx->h_scratch_bytes < stage_bytes) {
+			(void)hipStreamSynchronize(ctx->stream);
+			if (ctx->h_scratch)
+				(void)hipHostFree(ctx->h_scratch);
+			ctx->h_scratch = nullptr;
+			ctx->h_scratch_bytes = 0;
+			const size_t want = stage_bytes + stage_bytes / 4 + 4096;
+			if ((e = hipHostMalloc(&ctx->h_scratch, want, hipHostMallocDefault)) != hipSuccess) {
+				ctx->err = std::string("vgsdf_render_batch: hipHostMalloc: ") + hipGetErrorString(e);
+				delete b;
+				return VGSDF_E_OOM;
+			}
+			ctx->h_scratch_bytes = want;
+		}
+		b->d_arena = ctx->d_scratch;
+		b->h_stage = ctx->h_scratch;
+	} else {
+		e = hipMalloc(&b->d_arena, b->arena_bytes);
 		if (e != hipSuccess) {
-			ctx->err = std::string("vgsdf_batch_upload: hipHostMalloc: ") + hipGetErrorString(e);
-			vgsdf_batch_free(ctx, b);
+			ctx->err = std::string("vgsdf_batch_upload: hipMalloc: ") + hipGetErrorString(e);
+			delete b;
 			return VGSDF_E_OOM;
+		}
+		if (stage_bytes) {
+			e = hipHostMalloc(&b->h_stage, stage_bytes, hipHostMallocDefault);
+			if (e != hipSuccess) {
+				ctx->err = std::string("vgsdf_batch_upload: hipHostMalloc: ") + hipGetErrorString(e);
+				vgsdf_batch_free(ctx, b);
+				return VGSDF_E_OOM;
+			}
 		}
 	}
 	uint8_t *hs = (uint8_t *)b->h_stage, *da = (uint8_t *)b->d_arena;
@@ -281,13 +344,23 @@ int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			hd[g].h = in->h[g];
 			hd[g].out_off = in->out_off[g];
 		}
-		if (n_seg) {
+		if (n_seg && !direct) {
 			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
 			std::memcpy(hs + off_sy, in->seg_sy, sizeof(double) * n_seg);
 			std::memcpy(hs + off_ex, in->seg_ex, sizeof(double) * n_seg);
 			std::memcpy(hs + off_ey, in->seg_ey, sizeof(double) * n_seg);
 		}
-		e = hipMemcpyAsync(b->d_arena, b->h_stage, b->input_bytes, hipMemcpyHostToDevice, ctx->stream);
+		e = hipMemcpyAsync(b->d_arena, b->h_stage, stage_bytes, hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess && direct) {
+			const size_t nb = sizeof(double) * n_seg;
+			e = hipMemcpyAsync(b->d_sx, in->seg_sx, nb, hipMemcpyHostToDevice, ctx->stream);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(b->d_sy, in->seg_sy, nb, hipMemcpyHostToDevice, ctx->stream);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(b->d_ex, in->seg_ex, nb, hipMemcpyHostToDevice, ctx->stream);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(b->d_ey, in->seg_ey, nb, hipMemcpyHostToDevice, ctx->stream);
+		}
 		if (e != hipSuccess) {
 			ctx->err = std::string("vgsdf_batch_upload: H2D: ") + hipGetErrorString(e);
 			vgsdf_batch_free(ctx, b);
@@ -296,6 +369,27 @@ int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	}
 	*out = b;
 	return VGSDF_OK;
+}
+
+int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out)
+{
+	return upload_impl(ctx, in, out, false);
+}
+
+void *vgsdf_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return p;
+}
+
+void vgsdf_host_free(void *p)
+{
+	if (p)
+		(void)hipHostFree(p);
 }
 
 int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
@@ -372,7 +466,7 @@ int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitma
 	if (!ctx)
 		return VGSDF_E_ARG;
 	vgsdf_dbatch *b = nullptr;
-	int rc = vgsdf_batch_upload(ctx, in, &b);
+	int rc = upload_impl(ctx, in, &b, true);
 	if (rc != VGSDF_OK)
 		return rc;
 	rc = vgsdf_batch_launch(ctx, b);

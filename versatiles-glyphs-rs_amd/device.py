@@ -30,6 +30,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
+    "vgsdf_host_alloc", "vgsdf_host_free",
 ]
 
 _lib = None
@@ -62,6 +63,10 @@ def load_library():
         L.vgsdf_set_variant.argtypes = [vp, C.c_int]
         L.vgsdf_batch_device_output.argtypes = [vp]
         L.vgsdf_batch_device_output.restype = vp
+        L.vgsdf_host_alloc.argtypes = [C.c_size_t]
+        L.vgsdf_host_alloc.restype = vp
+        L.vgsdf_host_free.argtypes = [vp]
+        L.vgsdf_host_free.restype = None
         _lib = L
     return _lib
 

@@ -26,7 +26,7 @@ class PbfGlyph(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [(k, C.c_double) for k in ("tessellate_s", "device_s", "encode_s", "write_s", "total_s")] + \
+    _fields_ = [(k, C.c_double) for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s", "total_s")] + \
                [(k, C.c_uint64) for k in ("blocks", "glyphs", "rasters", "pixels", "segments", "pbf_bytes")]
 
     def as_dict(self):
