@@ -24,7 +24,8 @@ static_assert(sizeof(GlyphDesc) == 32, "GlyphDesc must stay 32 bytes");
 extern "C" int vgsdf_filtered_delta_cap(void);
 
 // tiles[i] = (glyph index, first output byte of the tile inside that glyph's bitmap)
-extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, const uint2 *tiles,
-                                  uint32_t n_tiles, const double *sx, const double *sy,
-                                  const double *ex, const double *ey, uint8_t *out,
+// list_order != 0: workgroups take tiles in list order; 0: per-XCD contiguous remap
+extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
+                                  const uint2 *tiles, uint32_t n_tiles, const double *sx,
+                                  const double *sy, const double *ex, const double *ey, uint8_t *out,
                                   hipStream_t stream);

@@ -30,9 +30,12 @@ constexpr int SEG_CHUNK = 512;         // segments per LDS stage: 7 * 512 * 8 B 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Remap so that
 // each XCD walks a contiguous range of tiles: tiles of one glyph (which re-read the same
 // segment list) then hit the same L2.  Pure performance hint; any placement is correct.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n_and_flag)
 {
 	constexpr uint32_t X = 8;
+	if (n_and_flag & 0x80000000u) // host asked for dispatch order == list order
+		return b;
+	const uint32_t n = n_and_flag;
 	uint32_t per = n / X, rem = n % X;
 	uint32_t xcd = b % X, idx = b / X;
 	// XCDs [0, rem) own per+1 tiles, the rest own per tiles
@@ -319,9 +322,12 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 
 		// ---- filter: sorted top-3 of (F | index) keys ----
 		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
+		uint32_t key_mask = ~IDX_MASK;
+		asm volatile("" : "+v"(key_mask)); // keep it in a VGPR (one SGPR/literal operand per VOP3 on gfx9)
 		auto consider = [&](float4 a, float len, uint32_t i) {
 			const float F = filter_dist_sq(rpx, rpy, a, len);
-			const uint32_t key = (__float_as_uint(F) & ~IDX_MASK) | (i & IDX_MASK);
+			uint32_t key; // (F & ~IDX_MASK) | i in one VALU op: the mask lives in a VGPR, i is wave-uniform
+			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(F)), "v"(key_mask), "s"(i));
 			// insert into the sorted quadruple: clamp(key, k_{j-1}, k_j) = med3
 			k4 = umed3(k3, k4, key);
 			k3 = umed3(k2, k3, key);
@@ -410,18 +416,21 @@ extern "C" int vgsdf_filtered_delta_cap(void) { return vgsdf::DELTA_CAP; }
 
 // variant 0: filtered kernel; variant 1: brute force (also the fallback for tiles the host
 // routes there: glyphs too wide for the winding histogram, or with >= 2^24 segments).
-extern "C" int vgsdf_launch_tiles(int variant, const vgsdf::GlyphDesc *glyphs, const uint2 *tiles,
-                                  uint32_t n_tiles, const double *sx, const double *sy,
-                                  const double *ex, const double *ey, uint8_t *out,
+extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
+                                  const uint2 *tiles, uint32_t n_tiles_in, const double *sx,
+                                  const double *sy, const double *ex, const double *ey, uint8_t *out,
                                   hipStream_t stream)
 {
-	if (n_tiles == 0)
+	if (n_tiles_in == 0)
 		return 0;
+	const dim3 grid(n_tiles_in);
+	// kernel argument: tile count, top bit set = dispatch in list order (no per-XCD remap)
+	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
 #define VG_LAUNCH_FILTERED(A)                                                                          \
-	hipLaunchKernelGGL(vgsdf::sdf_tiles_filtered<A>, dim3(n_tiles), dim3(vgsdf::TPB), 0, stream, glyphs, \
+	hipLaunchKernelGGL(vgsdf::sdf_tiles_filtered<A>, grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
 	if (variant == 1)
-		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, dim3(n_tiles), dim3(vgsdf::TPB), 0, stream, glyphs,
+		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
 		                   tiles, n_tiles, sx, sy, ex, ey, out);
 	else if (variant >= 100) { // timing-only ablations 100 + mask
 		switch (variant - 100) {

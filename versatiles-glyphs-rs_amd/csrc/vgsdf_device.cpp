@@ -3,7 +3,9 @@
 // product: if HIP is unusable every entry point reports VGSDF_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -57,6 +59,7 @@ struct vgsdf_dbatch {
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
 	uint32_t n_main = 0; // tiles [0, n_main) go to the filtered kernel, the rest to brute force
+	int tile_order = 1;
 	bool borrowed = false; // arena + staging belong to the context (vgsdf_render_batch)
 };
 
@@ -335,6 +338,17 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			if (pass == 0)
 				b->n_main = (uint32_t)ti;
 		}
+		// Heaviest tiles first (cost of a tile ~ its glyph's segment count): the dispatcher
+		// hands workgroups out in list order, so the long ones start early and the tail is
+		// made of short ones.  VGSDF_TILE_ORDER=0 keeps glyph order (+ per-XCD contiguous remap).
+		{
+			const char *ord = std::getenv("VGSDF_TILE_ORDER");
+			b->tile_order = ord ? std::atoi(ord) : 1;
+			if (b->tile_order != 0)
+				std::stable_sort(ht, ht + b->n_main, [&](const uint2 &a, const uint2 &c) {
+					return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
+				});
+		}
 		for (uint32_t g = 0; g < n; g++) {
 			hd[g].seg_off = in->seg_off[g];
 			hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
@@ -403,10 +417,11 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	(void)hipSetDevice(ctx->device);
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const uint32_t n_main = ctx->variant == 1 ? 0 : b->n_main;
-	int e = vgsdf_launch_tiles(ctx->variant >= 100 ? ctx->variant : 0, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_out,
+	const int list_order = b->tile_order == 1;
+	int e = vgsdf_launch_tiles(ctx->variant >= 100 ? ctx->variant : 0, list_order, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_out,
 	                           ctx->stream);
 	if (e == 0)
-		e = vgsdf_launch_tiles(1, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
+		e = vgsdf_launch_tiles(1, list_order, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
 		                       b->d_ey, b->d_out, ctx->stream);
 	if (e != 0) {
 		ctx->err = std::string("vgsdf_batch_launch: ") + hipGetErrorString((hipError_t)e);
