@@ -222,7 +222,7 @@ __device__ __forceinline__ float filter_err(float F, float M)
 
 // ABL: timing-only ablation mask (0 in production; non-zero variants give WRONG pixels):
 // 1 no winding pass, 2 no filter loop, 4 no exact evaluation, 16 no prefix loop
-template <int ABL>
+template <int ABL, bool CULL>
 __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__restrict__ glyphs,
                                                           const uint2 *__restrict__ tiles,
                                                           uint32_t n_tiles,
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 	__shared__ double s_vx[FCHUNK], s_vy[FCHUNK], s_wx[FCHUNK], s_wy[FCHUNK]; // exact endpoints
 	__shared__ int s_delta[DELTA_CAP];
 	__shared__ uint32_t s_mbits;
+	__shared__ __attribute__((aligned(8))) uint16_t s_list[TPB / 64][FCHUNK]; // per-wave candidate lists (CULL)
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
@@ -266,7 +267,9 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 	const float wh = (float)max(g.w, g.h);
 	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
 	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
+	const bool cull_pays = CULL; // the host routes only tiles of large glyphs to the CULL instance
 	double best = __builtin_huge_val(); // rtree_segments.rs:57
+	float ub = __builtin_inff();        // CULL: squared distance to the nearest sampled vertex so far
 
 	auto exact_lds = [&](uint32_t i) {
 		const double vx = s_vx[i], vy = s_vy[i], wx = s_wx[i], wy = s_wy[i];
@@ -320,47 +323,111 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 		}
 		__syncthreads();
 
-		// ---- filter: sorted top-3 of (F | index) keys ----
+		// ---- cull (per wave): which segments of the chunk can matter for THIS wave's pixels ----
+		// A segment is dropped only if its distance to every pixel of the wave's strip exceeds
+		// R, with R^2 >= min(UB, SAT^2) for every lane: UB = squared distance to some vertex
+		// (>= the true minimum, and that vertex's own segment is within R, so it stays), and
+		// SAT = 6.2 px (beyond 5.97 px outside / 2.02 px inside the byte is saturated whatever
+		// the minimum is: the reference's own +-8 px candidate rule, rtree_segments.rs:47-53).
+		uint32_t n_list = cnt;
+		const uint32_t wv = tid >> 6, lane = tid & 63;
+		const float Mc = __uint_as_float(s_mbits);
+		bool use_list = false;
+		if (cull_pays && Mc < 4096.0f) { // beyond that the f32 box test has no useful margin
+			use_list = true;
+			for (uint32_t j = 0; j < cnt; j += 8) { // every 8th start vertex
+				const float4 a = s_f[j];
+				const float ddx = rpx - a.x, ddy = rpy - a.y;
+				const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
+				ub = d2 < ub ? d2 : ub;
+			}
+			float r2 = ub < 38.44f ? ub : 38.44f; // SAT^2 = 6.2^2
+			for (int sh = 32; sh > 0; sh >>= 1) {
+				const float other = __shfl_xor(r2, sh);
+				r2 = other > r2 ? other : r2;
+			}
+			const float R2 = r2 * 1.01f + 0.02f; // covers the f32 rounding of UB and of the boxes (M < 4096)
+			const float delta = 4.0e-6f * Mc;
+			// the strip of pixels this wave owns (wave-uniform)
+			const uint32_t row_a = __builtin_amdgcn_readlane(row, 0), row_b = __builtin_amdgcn_readlane(row, 63);
+			const uint32_t x_a = __builtin_amdgcn_readlane(x, 0), x_b = __builtin_amdgcn_readlane(x, 63);
+			const float X0 = (row_a == row_b ? (float)x_a : 0.0f) + 0.5f;
+			const float X1 = (row_a == row_b ? (float)x_b : (float)(g.w - 1)) + 0.5f;
+			const float Y0 = (float)(g.h - 1 - row_b) + 0.5f, Y1 = (float)(g.h - 1 - row_a) + 0.5f;
+			n_list = 0;
+			for (uint32_t base = 0; base < cnt; base += 64) {
+				const uint32_t i = base + lane;
+				const bool valid = i < cnt;
+				const float4 a = s_f[valid ? i : 0];
+				const float len = s_len[valid ? i : 0];
+				const float wx = __builtin_fmaf(len, a.z, a.x), wy = __builtin_fmaf(len, a.w, a.y);
+				float gx = fmaxf(fminf(a.x, wx) - X1, X0 - fmaxf(a.x, wx)) - delta;
+				float gy = fmaxf(fminf(a.y, wy) - Y1, Y0 - fmaxf(a.y, wy)) - delta;
+				gx = gx > 0.0f ? gx : 0.0f;
+				gy = gy > 0.0f ? gy : 0.0f;
+				const float lb = __builtin_fmaf(gy, gy, gx * gx);
+				const bool pass = valid && !(lb > R2); // NaN passes
+				const unsigned long long m = __ballot(pass);
+				const uint32_t pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				if (pass)
+					s_list[wv][pos] = (uint16_t)i;
+				n_list += (uint32_t)__builtin_popcountll(m);
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+
+		// ---- filter: sorted top-4 of (F | index) keys over the listed segments ----
 		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
 		uint32_t key_mask = ~IDX_MASK;
 		asm volatile("" : "+v"(key_mask)); // keep it in a VGPR (one SGPR/literal operand per VOP3 on gfx9)
-		auto consider = [&](float4 a, float len, uint32_t i) {
-			const float F = filter_dist_sq(rpx, rpy, a, len);
-			uint32_t key; // (F & ~IDX_MASK) | i in one VALU op: the mask lives in a VGPR, i is wave-uniform
-			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(F)), "v"(key_mask), "s"(i));
-			// insert into the sorted quadruple: clamp(key, k_{j-1}, k_j) = med3
+		auto insert = [&](uint32_t key) { // sorted quadruple: clamp(key, k_{j-1}, k_j) = med3
 			k4 = umed3(k3, k4, key);
 			k3 = umed3(k2, k3, key);
 			k2 = umed3(k1, k2, key);
 			k1 = min(k1, key);
 		};
-		const uint32_t cnt_f = (ABL & 2) ? min(cnt, 4u) : cnt;
+		auto consider = [&](float4 a, float len, uint32_t i) { // i wave-uniform (SGPR)
+			const float F = filter_dist_sq(rpx, rpy, a, len);
+			uint32_t key; // (F & ~IDX_MASK) | i in one VALU op
+			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(F)), "v"(key_mask), "s"(i));
+			insert(key);
+		};
+		auto consider_v = [&](uint32_t i) { // i in a VGPR (read from the candidate list)
+			const float F = filter_dist_sq(rpx, rpy, s_f[i], s_len[i]);
+			uint32_t key;
+			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(F)), "v"(key_mask), "v"(i));
+			insert(key);
+		};
+		const uint32_t cnt_f = (ABL & 2) ? min(n_list, 4u) : n_list;
 		const uint32_t cnt4 = cnt_f & ~3u;
-		const float4 *s_len4 = reinterpret_cast<const float4 *>(s_len);
-		for (uint32_t i = 0; i < cnt4; i += 4) {
-			float4 a0 = s_f[i], a1, a2, a3, l;
-			if (ABL & 32) { // timing only: one LDS read per 4 segments
-				a1 = make_float4(a0.y, a0.x, a0.w, a0.z);
-				a2 = make_float4(a0.x + 1.0f, a0.y, a0.z, a0.w);
-				a3 = make_float4(a0.x, a0.y + 1.0f, a0.w, a0.z);
-				l = make_float4(a0.z, a0.w, a0.z, a0.w);
-			} else {
-				a1 = s_f[i + 1];
-				a2 = s_f[i + 2];
-				a3 = s_f[i + 3];
-				l = s_len4[i >> 2];
+		if (use_list) {
+			const uint2 *lst = reinterpret_cast<const uint2 *>(&s_list[wv][0]);
+			for (uint32_t j = 0; j < cnt4; j += 4) {
+				const uint2 ii = lst[j >> 2];
+				consider_v(ii.x & 0xFFFFu);
+				consider_v(ii.x >> 16);
+				consider_v(ii.y & 0xFFFFu);
+				consider_v(ii.y >> 16);
 			}
-			consider(a0, l.x, i);
-			consider(a1, l.y, i + 1);
-			consider(a2, l.z, i + 2);
-			consider(a3, l.w, i + 3);
+			for (uint32_t j = cnt4; j < cnt_f; j++)
+				consider_v(s_list[wv][j]);
+		} else {
+			const float4 *s_len4 = reinterpret_cast<const float4 *>(s_len);
+			for (uint32_t i = 0; i < cnt4; i += 4) {
+				const float4 a0 = s_f[i], a1 = s_f[i + 1], a2 = s_f[i + 2], a3 = s_f[i + 3];
+				const float4 l = s_len4[i >> 2];
+				consider(a0, l.x, i);
+				consider(a1, l.y, i + 1);
+				consider(a2, l.z, i + 2);
+				consider(a3, l.w, i + 3);
+			}
+			for (uint32_t i = cnt4; i < cnt_f; i++)
+				consider(s_f[i], s_len[i], i);
 		}
-		for (uint32_t i = cnt4; i < cnt_f; i++)
-			consider(s_f[i], s_len[i], i);
 
-		if (!(ABL & 4)) {
+		if (!(ABL & 4) && n_list > 0) {
 			// ---- exact evaluation of the candidates that cannot be excluded ----
-			const float M = __uint_as_float(s_mbits);
+			const float M = Mc;
 			const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
 			const float f1 = __uint_as_float(k1 & ~IDX_MASK) * KEY_SLACK;
 			float U = f1 + filter_err(f1, M) + e64;
@@ -370,12 +437,12 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 				const float fk = __uint_as_float(key & ~IDX_MASK);
 				return fk - filter_err(fk * KEY_SLACK, M) - e64 > U; // false for NaN / inf U
 			};
-			exact_lds(k1 & IDX_MASK); // cnt >= 1, so k1 is a real key
-			if (cnt >= 2 && !excluded(k2))
+			exact_lds(k1 & IDX_MASK); // n_list >= 1, so k1 is a real key
+			if (n_list >= 2 && !excluded(k2))
 				exact_lds(k2 & IDX_MASK);
-			if (cnt >= 3 && !excluded(k3))
+			if (n_list >= 3 && !excluded(k3))
 				exact_lds(k3 & IDX_MASK);
-			if (cnt >= 4 && !excluded(k4)) {
+			if (n_list >= 4 && !excluded(k4)) {
 				exact_lds(k4 & IDX_MASK);
 				// Four near-ties: more may hide behind them.  Rescan the chunk against a
 				// key threshold Tk with L(Tk) > U (L increasing above it): fixed-point
@@ -387,7 +454,8 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 				Tk = Tk * 1.001f + 1e-30f;
 				if (!(Tk - filter_err(Tk * KEY_SLACK, M) - e64 > U))
 					Tk = __builtin_inff();
-				for (uint32_t i = 0; i < ((ABL & 8) ? 0u : cnt); i++) {
+				for (uint32_t j = 0; j < ((ABL & 8) ? 0u : n_list); j++) {
+					const uint32_t i = use_list ? (uint32_t)s_list[wv][j] : j;
 					const float F = filter_dist_sq(rpx, rpy, s_f[i], s_len[i]);
 					const float fk = __uint_as_float(__float_as_uint(F) & ~IDX_MASK);
 					if (!(fk > Tk))
@@ -426,26 +494,28 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const dim3 grid(n_tiles_in);
 	// kernel argument: tile count, top bit set = dispatch in list order (no per-XCD remap)
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
-#define VG_LAUNCH_FILTERED(A)                                                                          \
-	hipLaunchKernelGGL(vgsdf::sdf_tiles_filtered<A>, grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
+#define VG_LAUNCH_FILTERED(A, C)                                                                          \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
 	if (variant == 1)
 		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
 		                   tiles, n_tiles, sx, sy, ex, ey, out);
 	else if (variant >= 100) { // timing-only ablations 100 + mask
 		switch (variant - 100) {
-		case 1: VG_LAUNCH_FILTERED(1); break;
-		case 2: VG_LAUNCH_FILTERED(2); break;
-		case 4: VG_LAUNCH_FILTERED(4); break;
-		case 6: VG_LAUNCH_FILTERED(6); break;
-		case 8: VG_LAUNCH_FILTERED(8); break;
-		case 36: VG_LAUNCH_FILTERED(36); break;
-		case 16: VG_LAUNCH_FILTERED(16); break;
-		case 23: VG_LAUNCH_FILTERED(23); break;
-		case 22: VG_LAUNCH_FILTERED(22); break;
-		default: VG_LAUNCH_FILTERED(0); break;
+		case 1: VG_LAUNCH_FILTERED(1, true); break;
+		case 2: VG_LAUNCH_FILTERED(2, true); break;
+		case 4: VG_LAUNCH_FILTERED(4, true); break;
+		case 6: VG_LAUNCH_FILTERED(6, true); break;
+		case 8: VG_LAUNCH_FILTERED(8, true); break;
+		case 36: VG_LAUNCH_FILTERED(36, true); break;
+		case 16: VG_LAUNCH_FILTERED(16, true); break;
+		case 23: VG_LAUNCH_FILTERED(23, true); break;
+		case 22: VG_LAUNCH_FILTERED(22, true); break;
+		default: VG_LAUNCH_FILTERED(0, true); break;
 		}
-	} else
-		VG_LAUNCH_FILTERED(0);
+	} else if (variant == 2) // filtered, no culling (A/B)
+		VG_LAUNCH_FILTERED(0, false);
+	else
+		VG_LAUNCH_FILTERED(0, true);
 	return (int)hipGetLastError();
 }

@@ -58,7 +58,9 @@ struct vgsdf_dbatch {
 	double *d_sx = nullptr, *d_sy = nullptr, *d_ex = nullptr, *d_ey = nullptr;
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
-	uint32_t n_main = 0; // tiles [0, n_main) go to the filtered kernel, the rest to brute force
+	// tile list = [filtered | filtered+culling | brute force]
+	uint32_t n_main = 0; // tiles [0, n_main): filtered kernel (both flavours)
+	uint32_t n_plain = 0; // tiles [0, n_plain): filtered without culling (small glyphs)
 	int tile_order = 1;
 	bool borrowed = false; // arena + staging belong to the context (vgsdf_render_batch)
 };
@@ -326,16 +328,31 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
 			return rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24);
 		};
+		// Culling (per-wave candidate lists) only pays when a wave's strip of 64 pixels plus the
+		// 6.2 px saturation margin covers well under half of the bitmap: large glyphs.  Small
+		// glyphs (every real font at 24 px/EM) take the straight broadcast loop.
+		auto wants_cull = [&](uint32_t g) {
+			const float w = (float)in->w[g], h = (float)in->h[g];
+			if (w <= 0.0f || h <= 0.0f)
+				return false;
+			const float strip_rows = (float)((63u + in->w[g]) / in->w[g] + 1u);
+			const float keep_y = std::min(1.0f, (strip_rows + 12.4f) / h);
+			const float keep_x = in->w[g] <= 64u ? 1.0f : std::min(1.0f, 76.4f / w);
+			return keep_x * keep_y < 0.40f;
+		};
 		uint64_t ti = 0;
-		for (int pass = 0; pass < 2; pass++) {
+		for (int pass = 0; pass < 3; pass++) {
 			for (uint32_t g = 0; g < n; g++) {
-				if ((int)wants_brute(g) != pass)
+				const int cls = wants_brute(g) ? 2 : (wants_cull(g) ? 1 : 0);
+				if (cls != pass)
 					continue;
 				const uint32_t px = in->w[g] * in->h[g];
 				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
 					ht[ti++] = make_uint2(g, p);
 			}
 			if (pass == 0)
+				b->n_plain = (uint32_t)ti;
+			if (pass == 1)
 				b->n_main = (uint32_t)ti;
 		}
 		// Heaviest tiles first (cost of a tile ~ its glyph's segment count): the dispatcher
@@ -344,10 +361,13 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 		{
 			const char *ord = std::getenv("VGSDF_TILE_ORDER");
 			b->tile_order = ord ? std::atoi(ord) : 1;
-			if (b->tile_order != 0)
-				std::stable_sort(ht, ht + b->n_main, [&](const uint2 &a, const uint2 &c) {
-					return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
-				});
+			auto heavier = [&](const uint2 &a, const uint2 &c) {
+				return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
+			};
+			if (b->tile_order != 0) {
+				std::stable_sort(ht, ht + b->n_plain, heavier);
+				std::stable_sort(ht + b->n_plain, ht + b->n_main, heavier);
+			}
 		}
 		for (uint32_t g = 0; g < n; g++) {
 			hd[g].seg_off = in->seg_off[g];
@@ -415,11 +435,18 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_E_ARG;
 	}
 	(void)hipSetDevice(ctx->device);
+	// variant 0: routed (plain / culled / brute); 1: everything brute; 2: filtered, never culled;
+	// 3: filtered, always culled; >= 100: timing-only ablations of the culled instance
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
-	const uint32_t n_main = ctx->variant == 1 ? 0 : b->n_main;
+	const int v = ctx->variant;
+	const uint32_t n_main = v == 1 ? 0 : b->n_main;
+	const uint32_t n_plain = v == 1 ? 0 : (v == 2 ? n_main : ((v == 3 || v >= 100) ? 0 : b->n_plain));
 	const int list_order = b->tile_order == 1;
-	int e = vgsdf_launch_tiles(ctx->variant >= 100 ? ctx->variant : 0, list_order, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_out,
-	                           ctx->stream);
+	int e = vgsdf_launch_tiles(2, list_order, b->d_glyphs, b->d_tiles, n_plain, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
+	                           b->d_out, ctx->stream);
+	if (e == 0)
+		e = vgsdf_launch_tiles(v >= 100 ? v : 0, list_order, b->d_glyphs, b->d_tiles + n_plain, n_main - n_plain, b->d_sx,
+		                       b->d_sy, b->d_ex, b->d_ey, b->d_out, ctx->stream);
 	if (e == 0)
 		e = vgsdf_launch_tiles(1, list_order, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
 		                       b->d_ey, b->d_out, ctx->stream);
