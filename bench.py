@@ -33,7 +33,11 @@ WORKLOADS = {
     "noto_regular": ("Noto Sans Regular", ["Noto Sans/Noto Sans - Regular.ttf"]),
     "fira": ("Fira Sans Regular", ["Fira Sans - Regular.ttf"]),
     "noto_all": ("Noto Sans Regular", None),  # all 20 files of testdata/Noto Sans, sorted
+    # BASELINE.json configs[4]: 65 536 outlines x 1024 segments at 70x70, split over 8 GPUs ->
+    # 8192 outlines per rank (synthetic.py; generated on the host, no font involved)
+    "synthetic": ("synthetic stress outlines", []),
 }
+SYNTHETIC_PER_RANK = 8192
 
 
 def load_product():
@@ -78,6 +82,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--synthetic-outlines", type=int, default=0, help="outlines per rank for --workload synthetic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,10 +107,19 @@ def main():
 
     # ---- host stage (product C++): fonts -> SoA batch ---------------------------------
     disp, paths = workload_files(args.workload)
-    mgr = vg.FontManager(True)
-    fid = mgr.add_font_with_name(disp, paths)
+    synthetic = args.workload == "synthetic"
     t0 = time.perf_counter()
-    hb = mgr.build_batch(fid)
+    if synthetic:
+        from versatiles_glyphs_rs_amd import synthetic as S
+        n_out = args.synthetic_outlines or SYNTHETIC_PER_RANK
+        class _HB:  # same shape as GlyphBatchHost: .batch
+            batch = S.make_batch(rank * n_out, n_out)   # rank r renders outlines [r*n, (r+1)*n)
+        hb, mgr, fid = _HB, None, None
+        args.no_e2e = True
+    else:
+        mgr = vg.FontManager(True)
+        fid = mgr.add_font_with_name(disp, paths)
+        hb = mgr.build_batch(fid)
     host_s = time.perf_counter() - t0
 
     ctx = vg.SdfContext(local_rank)
@@ -151,7 +165,8 @@ def main():
     flop = 16.0 * st["n_pairs"]
 
     out = {
-        "metric": "glyphs/sec (SDF raster, Noto Sans Regular full BMP set)",
+        "metric": "glyphs/sec (SDF raster, Noto Sans Regular full BMP set)" if args.workload == "noto_regular"
+                  else f"glyphs/sec (SDF raster, {args.workload})",
         "value": value,
         "unit": "glyphs/s",
         "n_gpus": world,
@@ -162,9 +177,11 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "reference testdata font committed in-repo (no network); every rank renders its own replica",
+        "data": ("synthetic outlines (SplitMix64 seed 0x5DF61F95), each rank its own index range" if synthetic else
+                 "reference testdata font committed in-repo (no network); every rank renders its own replica"),
         "config": {
-            "workload": f"{args.workload}: {disp}, {len(paths)} file(s), all BMP code points",
+            "workload": (f"synthetic: {st['n_glyphs']} outlines x 1024 segments, 70x70 px per rank" if synthetic else
+                         f"{args.workload}: {disp}, {len(paths)} file(s), all BMP code points"),
             "glyphs_per_step_per_gpu": st["n_glyphs"],
             "segments": st["n_segments"],
             "pixels": st["n_pixels"],
@@ -204,21 +221,29 @@ def main():
         from oracle import oracle as O
         cores = O.default_threads()
         got = db.download()
+        sample, n_sample = hb.batch, st["n_glyphs"]
+        if synthetic:  # bounded sample: the first 256 outlines of this rank's range (~10 s of CPU work)
+            from versatiles_glyphs_rs_amd import synthetic as S
+            n_sample = min(256, st["n_glyphs"])
+            sample = S.make_batch(rank * (args.synthetic_outlines or SYNTHETIC_PER_RANK), n_sample)
+            got = got[:sample.out_bytes]
         best = None
-        for mode, label in ((O.BRUTE, "all segments"), (O.PRECISE, "±8 px envelope filter")):
-            ref, secs = O.sdf_render_batch(hb.batch, mode, cores)
+        for mode, label in ((O.PRECISE, "±8 px envelope filter"), (O.BRUTE, "all segments")):
+            if synthetic and mode == O.BRUTE:
+                continue
+            ref, secs = O.sdf_render_batch(sample, mode, cores)
             if not (ref == got).all():
                 out["parity"] = f"MISMATCH vs oracle ({label})"
             if best is None or secs < best[0]:
                 best = (secs, label)
-        out.setdefault("parity", "bit-exact vs oracle on the benchmarked batch")
+        out.setdefault("parity", "bit-exact vs oracle on the compared sample")
         out["cpu_baseline"] = {
-            "value": st["n_glyphs"] / best[0],
+            "value": n_sample / best[0],
             "unit": "glyphs/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"the full {args.workload} batch once ({st['n_glyphs']} glyphs, raster only, same "
-                      f"tessellated segments; faster of the oracle's two candidate rules: {best[1]})",
+            "sample": f"{n_sample} glyphs of the {args.workload} batch, once, raster only, same tessellated "
+                      f"segments; faster of the oracle's candidate rules: {best[1]}",
             "seconds": best[0],
         }
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

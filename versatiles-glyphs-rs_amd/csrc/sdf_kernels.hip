@@ -475,6 +475,350 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 	}
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 0 (default since the packed rewrite): same algorithm and the same exactness
+// argument as sdf_tiles_filtered, with the f32 filter evaluated for TWO segments per VALU
+// instruction (v_pk_add/mul/fma_f32 issue at the scalar rate on gfx950 — measured,
+// tools/ubench/valu_rate.hip — so the 9 filter ops cost 4.5 issue slots per segment).
+//
+// Filter record (SoA in LDS, read as float4 = two packed pairs per array):
+//   v (start, relative to the glyph origin), d = w - v, inv = 1/|d|^2 (0 when degenerate)
+//   t = clamp(((p-v).d) * inv, 0, 1)  [v_pk_mul_f32 ... clamp],  F = |(p-v) - t d|^2.
+// Error bound: the record's end points are within 4.25uM + u|d| <= 7.1uM of the true ones
+// (tighter than the unit-direction form), the parameter error is again second order, so
+// h(F) = 64uM sqrt(F) + 32uF + 2^-34 M^2 holds with more slack.
+// CULL: each wave compacts the records that can matter for its strip into its own SoA
+// arrays (plus their indices) and then runs the very same packed loop over them.
+// ---------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_filter(f2 rpx, f2 rpy, f2 vx, f2 vy, f2 dx, f2 dy, f2 inv)
+{
+	const f2 pvx = rpx - vx, pvy = rpy - vy;
+	const f2 dot = __builtin_elementwise_fma(pvy, dy, pvx * dx);
+	f2 t;
+	asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(dot), "v"(inv)); // clamp to [0,1]; NaN -> 0
+	const f2 ex = __builtin_elementwise_fma(-t, dx, pvx), ey = __builtin_elementwise_fma(-t, dy, pvy);
+	return __builtin_elementwise_fma(ey, ey, ex * ex);
+}
+
+__device__ __forceinline__ float sc_filter(float rpx, float rpy, float vx, float vy, float dx, float dy, float inv)
+{
+	const float pvx = rpx - vx, pvy = rpy - vy;
+	const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(pvy, dy, pvx * dx) * inv, 0.0f, 1.0f);
+	const float ex = __builtin_fmaf(-t, dx, pvx), ey = __builtin_fmaf(-t, dy, pvy);
+	return __builtin_fmaf(ey, ey, ex * ex);
+}
+
+template <int ABL, bool CULL>
+__global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict__ glyphs,
+                                                    const uint2 *__restrict__ tiles, uint32_t n_tiles,
+                                                    const double *__restrict__ seg_sx,
+                                                    const double *__restrict__ seg_sy,
+                                                    const double *__restrict__ seg_ex,
+                                                    const double *__restrict__ seg_ey,
+                                                    uint8_t *__restrict__ out)
+{
+	constexpr int NW = TPB / 64;
+	// filter records of the chunk, SoA
+	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
+	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
+	__shared__ int s_delta[DELTA_CAP];
+	__shared__ uint32_t s_mbits;
+	// CULL: per-wave compacted records + their chunk indices
+	__shared__ __attribute__((aligned(16))) float c_rec[CULL ? NW : 1][5][CULL ? FCHUNK : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t c_idx[CULL ? NW : 1][CULL ? FCHUNK : 4];
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
+	const uint2 t = tiles[tile];
+	const GlyphDesc g = glyphs[t.x];
+	const uint32_t npix = g.w * g.h;
+	const uint32_t o = t.y + tid;
+	const bool active = o < npix;
+	const uint32_t oc = active ? o : npix - 1;
+	const uint32_t row = oc / g.w;
+	const uint32_t x = oc - row * g.w;
+	const uint32_t y = g.h - 1 - row;
+	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
+	const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
+	const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
+	const f2 rpx2 = {rpx, rpx}, rpy2 = {rpy, rpy};
+
+	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
+	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
+	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
+	const uint32_t stride = g.w + 1;
+	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
+	for (uint32_t i = tid; i < n_delta; i += TPB)
+		s_delta[i] = 0;
+
+	const float wh = (float)max(g.w, g.h);
+	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
+	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
+	double best = __builtin_huge_val(); // rtree_segments.rs:57
+	float ub = __builtin_inff();        // CULL: squared distance to the nearest sampled vertex so far
+	const uint32_t wv = tid >> 6, lane = tid & 63;
+
+	auto exact_lds = [&](uint32_t i) {
+		const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
+		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
+		const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
+		best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
+	};
+
+	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
+		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
+		__syncthreads(); // previous chunk fully consumed (and s_delta zeroed on the first trip)
+		if (tid == 0)
+			s_mbits = __float_as_uint(wh);
+		__syncthreads();
+
+		// ---- stage: exact endpoints, f32 filter records, coordinate bound, row crossings ----
+		for (uint32_t i = tid; i < FCHUNK; i += TPB) {
+			if (i >= cnt) { // pad to a multiple of 4 with records that can never win (F = 2e36)
+				s_vx[i] = 1.0e18f;
+				s_vy[i] = 1.0e18f;
+				s_dx[i] = 0.0f;
+				s_dy[i] = 0.0f;
+				s_inv[i] = 0.0f;
+				continue;
+			}
+			const uint32_t s = g.seg_off + c0 + i;
+			const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
+			e_vx[i] = vx;
+			e_vy[i] = vy;
+			e_wx[i] = wx;
+			e_wy[i] = wy;
+			const double dx = wx - vx, dy = wy - vy;
+			const double l2 = dx * dx + dy * dy;
+			const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
+			const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
+			s_vx[i] = (float)rvx;
+			s_vy[i] = (float)rvy;
+			s_dx[i] = (float)dx;
+			s_dy[i] = (float)dy;
+			s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
+			const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
+			float mf = (float)m * 1.000001f;         // round up
+			mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
+			atomicMax(&s_mbits, __float_as_uint(mf)); // non-negative floats order like uints
+			// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
+			if (!(ABL & 1) && vy != wy) {
+				const bool up = vy < wy;
+				const double lo = up ? vy : wy, hi = up ? wy : vy;
+				const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
+				const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
+				for (int yy = ya; yy < yb; yy++) {
+					const double pyy = (double)yy + y0c;
+					const double tc = (pyy - vy) / dy;
+					const double xc = vx + tc * dx;               // :45-46 / :48-49
+					const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
+					if (k < (int)g.w)
+						atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
+				}
+			}
+		}
+		__syncthreads();
+		const float Mc = __uint_as_float(s_mbits);
+		const bool sane = Mc < 1.0e6f; // else: no usable f32 bound -> every segment is evaluated exactly
+
+		// ---- which arrays does this wave scan? the chunk's, or its own compacted copy ----
+		const float *a_vx = s_vx, *a_vy = s_vy, *a_dx = s_dx, *a_dy = s_dy, *a_inv = s_inv;
+		uint32_t n_list = cnt;
+		bool use_list = false;
+		if (CULL && Mc < 4096.0f) {
+			// A segment is dropped only if its distance to every pixel of the wave's strip exceeds
+			// R, with R^2 >= min(UB, SAT^2) for every lane: UB = squared distance to some vertex
+			// (>= the true minimum, and that vertex's own segment is within R, so it stays), and
+			// SAT = 6.2 px (beyond 5.97 px outside / 2.02 px inside the byte is saturated whatever
+			// the minimum is: the reference's own +-8 px candidate rule, rtree_segments.rs:47-53).
+			use_list = true;
+			for (uint32_t j = 0; j < cnt; j += 8) { // every 8th start vertex
+				const float ddx = rpx - s_vx[j], ddy = rpy - s_vy[j];
+				const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
+				ub = d2 < ub ? d2 : ub;
+			}
+			float r2 = ub < 38.44f ? ub : 38.44f; // SAT^2 = 6.2^2
+			for (int sh = 32; sh > 0; sh >>= 1) {
+				const float other = __shfl_xor(r2, sh);
+				r2 = other > r2 ? other : r2;
+			}
+			const float R2 = r2 * 1.01f + 0.02f; // covers the f32 rounding of UB and of the boxes (M < 4096)
+			const float delta = 4.0e-6f * Mc;
+			const uint32_t row_a = __builtin_amdgcn_readlane(row, 0), row_b = __builtin_amdgcn_readlane(row, 63);
+			const uint32_t x_a = __builtin_amdgcn_readlane(x, 0), x_b = __builtin_amdgcn_readlane(x, 63);
+			const float X0 = (row_a == row_b ? (float)x_a : 0.0f) + 0.5f;
+			const float X1 = (row_a == row_b ? (float)x_b : (float)(g.w - 1)) + 0.5f;
+			const float Y0 = (float)(g.h - 1 - row_b) + 0.5f, Y1 = (float)(g.h - 1 - row_a) + 0.5f;
+			n_list = 0;
+			for (uint32_t base = 0; base < cnt; base += 64) {
+				const uint32_t i = base + lane;
+				const bool valid = i < cnt;
+				const uint32_t ic = valid ? i : 0;
+				const float vx = s_vx[ic], vy = s_vy[ic], dx = s_dx[ic], dy = s_dy[ic], inv = s_inv[ic];
+				const float wx = vx + dx, wy = vy + dy;
+				float gx = fmaxf(fminf(vx, wx) - X1, X0 - fmaxf(vx, wx)) - delta;
+				float gy = fmaxf(fminf(vy, wy) - Y1, Y0 - fmaxf(vy, wy)) - delta;
+				gx = gx > 0.0f ? gx : 0.0f;
+				gy = gy > 0.0f ? gy : 0.0f;
+				const float lb = __builtin_fmaf(gy, gy, gx * gx);
+				const bool pass = valid && !(lb > R2); // NaN passes
+				const unsigned long long m = __ballot(pass);
+				const uint32_t pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				if (pass) {
+					c_rec[wv][0][pos] = vx;
+					c_rec[wv][1][pos] = vy;
+					c_rec[wv][2][pos] = dx;
+					c_rec[wv][3][pos] = dy;
+					c_rec[wv][4][pos] = inv;
+					c_idx[wv][pos] = i;
+				}
+				n_list += (uint32_t)__builtin_popcountll(m);
+			}
+			// pad the compacted arrays to a multiple of 8 (one group) with records that never win
+			if (lane < 8) {
+				const uint32_t pos = n_list + lane;
+				if (pos < ((n_list + 7u) & ~7u)) {
+					c_rec[wv][0][pos] = 1.0e18f;
+					c_rec[wv][1][pos] = 1.0e18f;
+					c_rec[wv][2][pos] = 0.0f;
+					c_rec[wv][3][pos] = 0.0f;
+					c_rec[wv][4][pos] = 0.0f;
+					c_idx[wv][pos] = 0;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			a_vx = c_rec[wv][0];
+			a_vy = c_rec[wv][1];
+			a_dx = c_rec[wv][2];
+			a_dy = c_rec[wv][3];
+			a_inv = c_rec[wv][4];
+		}
+
+		// ---- level 1: per group of 8 segments keep only the smallest F; sorted top-3 of the
+		// group minima (F | group id).  Selection ops (min/med3: half rate, serially dependent)
+		// drop from 4 per segment to 1 per segment; the packed filter does the rest. ----
+		constexpr uint32_t GRP = 8, GMASK = (FCHUNK / GRP) - 1; // 32 groups per chunk -> 5 id bits
+		constexpr float GSLACK = 1.0f + 1.0f / 262144.0f + 1.0f / 4194304.0f; // >= (1 + 2^-18)(1 + 2^-23)
+		const uint32_t n8 = (n_list + GRP - 1) & ~(GRP - 1); // padded records (F = 2e36) never win
+		const uint32_t n_groups = n8 / GRP;
+		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu;
+		uint32_t gmask_v = ~GMASK;
+		asm volatile("" : "+v"(gmask_v)); // VGPR operand (one SGPR/literal per VOP3 on gfx9)
+		const float4 *q_vx = reinterpret_cast<const float4 *>(a_vx), *q_vy = reinterpret_cast<const float4 *>(a_vy);
+		const float4 *q_dx = reinterpret_cast<const float4 *>(a_dx), *q_dy = reinterpret_cast<const float4 *>(a_dy);
+		const float4 *q_inv = reinterpret_cast<const float4 *>(a_inv);
+		auto umin3 = [](uint32_t a, uint32_t b, uint32_t c) {
+			uint32_t r;
+			asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+			return r;
+		};
+		auto quad = [&](uint32_t q, f2 &Fa, f2 &Fb) { // records 4q .. 4q+3
+			const float4 vx = q_vx[q], vy = q_vy[q], dx = q_dx[q], dy = q_dy[q], iv = q_inv[q];
+			Fa = pk_filter(rpx2, rpy2, f2{vx.x, vx.y}, f2{vy.x, vy.y}, f2{dx.x, dx.y}, f2{dy.x, dy.y}, f2{iv.x, iv.y});
+			Fb = pk_filter(rpx2, rpy2, f2{vx.z, vx.w}, f2{vy.z, vy.w}, f2{dx.z, dx.w}, f2{dy.z, dy.w}, f2{iv.z, iv.w});
+		};
+		for (uint32_t gi = 0; gi < ((ABL & 2) ? min(n_groups, 1u) : n_groups); gi++) {
+			f2 Fa, Fb, Fc, Fd;
+			quad(2 * gi, Fa, Fb);
+			quad(2 * gi + 1, Fc, Fd);
+			// F >= +0: unsigned order of the bits is float order; NaN bits sort above +inf
+			uint32_t m = umin3(__float_as_uint(Fa.x), __float_as_uint(Fa.y), __float_as_uint(Fb.x));
+			m = umin3(m, __float_as_uint(Fb.y), __float_as_uint(Fc.x));
+			m = umin3(m, __float_as_uint(Fc.y), __float_as_uint(Fd.x));
+			m = min(m, __float_as_uint(Fd.y));
+			uint32_t gkey;
+			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(gkey) : "v"(m), "v"(gmask_v), "s"(gi));
+			k3 = umed3(k2, k3, gkey); // sorted triple: clamp(key, k_{j-1}, k_j)
+			k2 = umed3(k1, k2, gkey);
+			k1 = min(k1, gkey);
+		}
+
+		if (!(ABL & 4) && n_list > 0) {
+			const float M = Mc;
+			const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
+			// U >= min over all segments of C: the best group's minimum is a real segment's F
+			const float f1 = __uint_as_float(k1 & ~GMASK) * GSLACK;
+			float U = f1 + filter_err(f1, M) + e64;
+			if (!sane || !(U >= 0.0f))
+				U = __builtin_inff();
+			auto excluded = [&](float fk) { // fk <= the true filter value <= fk * GSLACK
+				return fk - filter_err(fk * GSLACK, M) - e64 > U; // false for NaN / inf U
+			};
+			bool rescan = !sane; // keys are meaningless without a bound: evaluate everything
+			if (sane) {
+				// ---- level 2: inside every group whose minimum cannot be excluded, sorted top-4
+				// of (F | position) over its 8 members (lane-divergent LDS reads) ----
+				uint32_t q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu, q3 = 0xFFFFFFFFu, q4 = 0xFFFFFFFFu;
+				const bool g2 = n_groups >= 2 && !excluded(__uint_as_float(k2 & ~GMASK));
+				const bool g3 = n_groups >= 3 && !excluded(__uint_as_float(k3 & ~GMASK));
+				if (g3 && n_groups > 3)
+					rescan = true; // a 4th group (and more) may hold candidates too
+				for (uint32_t j = 0; j < 3; j++) {
+					const bool take = j == 0 || (j == 1 ? g2 : g3);
+					if (take && !rescan) {
+						const uint32_t gbase = ((j == 0 ? k1 : (j == 1 ? k2 : k3)) & GMASK) * GRP;
+						for (uint32_t mth = 0; mth < GRP; mth++) {
+							const uint32_t pos = gbase + mth;
+							const float F = sc_filter(rpx, rpy, a_vx[pos], a_vy[pos], a_dx[pos], a_dy[pos], a_inv[pos]);
+							const uint32_t key = (__float_as_uint(F) & ~31u) | (j * GRP + mth); // 5 position bits
+							q4 = umed3(q3, q4, key);
+							q3 = umed3(q2, q3, key);
+							q2 = umed3(q1, q2, key);
+							q1 = min(q1, key);
+						}
+					}
+				}
+				if (!rescan) {
+					auto seg_of = [&](uint32_t key) { // position in the scanned arrays -> chunk index
+						const uint32_t jj = (key & 31u) / GRP, mm = key & (GRP - 1);
+						const uint32_t pos = ((jj == 0 ? k1 : (jj == 1 ? k2 : k3)) & GMASK) * GRP + mm;
+						return use_list ? c_idx[CULL ? wv : 0][pos] : pos;
+					};
+					// q1 is the overall best filter value of a real segment (never a padded record)
+					exact_lds(seg_of(q1));
+					const bool s2 = !excluded(__uint_as_float(q2 & ~31u)), s3 = !excluded(__uint_as_float(q3 & ~31u));
+					const bool s4 = !excluded(__uint_as_float(q4 & ~31u));
+					if (q2 != 0xFFFFFFFFu && s2)
+						exact_lds(seg_of(q2));
+					if (q3 != 0xFFFFFFFFu && s3)
+						exact_lds(seg_of(q3));
+					if (q4 != 0xFFFFFFFFu && s4) {
+						exact_lds(seg_of(q4));
+						rescan = true; // four near-ties: more may hide behind them
+					}
+				}
+			}
+			if (rescan) {
+				// Rescan against a threshold Tk with L(Tk) > U (L increasing above it): fixed-point
+				// iteration for the crossing, pushed up, then VERIFIED; if the check fails nothing
+				// is excluded (Tk = inf).
+				float Tk = U + e64;
+				for (int it = 0; it < 3; it++)
+					Tk = U + e64 + filter_err(Tk * GSLACK, M);
+				Tk = Tk * 1.001f + 1e-30f;
+				if (!(Tk - filter_err(Tk * GSLACK, M) - e64 > U))
+					Tk = __builtin_inff();
+				for (uint32_t j = 0; j < ((ABL & 8) ? 0u : n_list); j++) {
+					const float F = sc_filter(rpx, rpy, a_vx[j], a_vy[j], a_dx[j], a_dy[j], a_inv[j]);
+					if (!(F > Tk))
+						exact_lds(use_list ? c_idx[CULL ? wv : 0][j] : j);
+				}
+			}
+		}
+	}
+
+	if (active) {
+		// winding number = prefix sum of the row's histogram up to this column
+		int wn = 0;
+		const int *drow = s_delta + (row - r_first) * stride;
+		for (uint32_t k = 0; k <= ((ABL & 16) ? 0u : x); k++)
+			wn += drow[k];
+		out[g.out_off + o] = quantise(best, wn != 0);
+	}
+}
+
 } // namespace vgsdf
 
 // ---------------------------------------------------------------------------------------
@@ -494,6 +838,9 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const dim3 grid(n_tiles_in);
 	// kernel argument: tile count, top bit set = dispatch in list order (no per-XCD remap)
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
+#define VG_LAUNCH_PK(A, C)                                                                              \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles, \
+	                   sx, sy, ex, ey, out)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
@@ -513,9 +860,21 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		case 22: VG_LAUNCH_FILTERED(22, true); break;
 		default: VG_LAUNCH_FILTERED(0, true); break;
 		}
-	} else if (variant == 2) // filtered, no culling (A/B)
+	} else if (variant == 2) // packed filter, no culling
+		VG_LAUNCH_PK(0, false);
+	else if (variant == 12) // previous generation: scalar filter, no culling (A/B)
 		VG_LAUNCH_FILTERED(0, false);
-	else
+	else if (variant == 10)
 		VG_LAUNCH_FILTERED(0, true);
+	else if (variant == 54)
+		VG_LAUNCH_PK(4, false);
+	else if (variant == 55)
+		VG_LAUNCH_PK(36, false);
+	else if (variant == 56)
+		VG_LAUNCH_PK(68, false);
+	else if (variant == 57)
+		VG_LAUNCH_PK(100, false);
+	else
+		VG_LAUNCH_PK(0, true);
 	return (int)hipGetLastError();
 }

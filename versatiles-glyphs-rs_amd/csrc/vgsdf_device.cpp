@@ -435,17 +435,21 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_E_ARG;
 	}
 	(void)hipSetDevice(ctx->device);
-	// variant 0: routed (plain / culled / brute); 1: everything brute; 2: filtered, never culled;
-	// 3: filtered, always culled; >= 100: timing-only ablations of the culled instance
+	// variant 0: routed (plain / culled / brute); 1: everything brute; 2: packed filter, never
+	// culled; 3: packed filter, always culled; 12 / 13: previous-generation scalar filter
+	// (never / always culled) for A/B; 54: timing-only (packed, no exact evaluation);
+	// >= 100: timing-only ablations of the scalar culled instance
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
-	const uint32_t n_plain = v == 1 ? 0 : (v == 2 ? n_main : ((v == 3 || v >= 100) ? 0 : b->n_plain));
+	const bool all_plain = v == 2 || v == 12 || (v >= 54 && v <= 57), all_cull = v == 3 || v == 13 || v >= 100;
+	const uint32_t n_plain = v == 1 ? 0 : (all_plain ? n_main : (all_cull ? 0 : b->n_plain));
 	const int list_order = b->tile_order == 1;
-	int e = vgsdf_launch_tiles(2, list_order, b->d_glyphs, b->d_tiles, n_plain, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
+	const int k_plain = v == 12 ? 12 : ((v >= 54 && v <= 57) ? v : 2), k_cull = v >= 100 ? v : (v == 13 ? 10 : 0);
+	int e = vgsdf_launch_tiles(k_plain, list_order, b->d_glyphs, b->d_tiles, n_plain, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
 	                           b->d_out, ctx->stream);
 	if (e == 0)
-		e = vgsdf_launch_tiles(v >= 100 ? v : 0, list_order, b->d_glyphs, b->d_tiles + n_plain, n_main - n_plain, b->d_sx,
+		e = vgsdf_launch_tiles(k_cull, list_order, b->d_glyphs, b->d_tiles + n_plain, n_main - n_plain, b->d_sx,
 		                       b->d_sy, b->d_ex, b->d_ey, b->d_out, ctx->stream);
 	if (e == 0)
 		e = vgsdf_launch_tiles(1, list_order, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
