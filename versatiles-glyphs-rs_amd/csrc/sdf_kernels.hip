@@ -510,17 +510,20 @@ __device__ __forceinline__ float sc_filter(float rpx, float rpy, float vx, float
 	return __builtin_fmaf(ey, ey, ex * ex);
 }
 
-template <int ABL, bool CULL>
-__global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict__ glyphs,
-                                                    const uint2 *__restrict__ tiles, uint32_t n_tiles,
-                                                    const double *__restrict__ seg_sx,
-                                                    const double *__restrict__ seg_sy,
-                                                    const double *__restrict__ seg_ex,
-                                                    const double *__restrict__ seg_ey,
-                                                    uint8_t *__restrict__ out)
+template <int ABL, bool CULL, int PPL>
+__global__ __launch_bounds__(TPB / PPL) void sdf_tiles_pk(const GlyphDesc *__restrict__ glyphs,
+                                                          const uint2 *__restrict__ tiles, uint32_t n_tiles,
+                                                          const double *__restrict__ seg_sx,
+                                                          const double *__restrict__ seg_sy,
+                                                          const double *__restrict__ seg_ex,
+                                                          const double *__restrict__ seg_ey,
+                                                          uint8_t *__restrict__ out)
 {
-	constexpr int NW = TPB / 64;
-	// filter records of the chunk, SoA
+	// PPL pixels per lane (adjacent output bytes): every LDS broadcast read of a segment
+	// record then serves 64 * PPL pixels.  With PPL = 1 the grouped loop is LDS-bandwidth
+	// bound (10 ds_read_b128 per 8 segments per wave); PPL = 2 halves that traffic.
+	constexpr int NT = TPB / PPL; // threads per workgroup; the tile is still TPB pixels
+	constexpr int NW = NT / 64;
 	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
 	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
 	__shared__ int s_delta[DELTA_CAP];
@@ -534,37 +537,54 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict_
 	const uint2 t = tiles[tile];
 	const GlyphDesc g = glyphs[t.x];
 	const uint32_t npix = g.w * g.h;
-	const uint32_t o = t.y + tid;
-	const bool active = o < npix;
-	const uint32_t oc = active ? o : npix - 1;
-	const uint32_t row = oc / g.w;
-	const uint32_t x = oc - row * g.w;
-	const uint32_t y = g.h - 1 - row;
 	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
-	const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
-	const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
-	const f2 rpx2 = {rpx, rpx}, rpy2 = {rpy, rpy};
+
+	uint32_t o[PPL], row[PPL], x[PPL];
+	bool active[PPL];
+	double px[PPL], py[PPL];
+	float rpx[PPL], rpy[PPL];
+	f2 rpx2[PPL], rpy2[PPL];
+#pragma unroll
+	for (int p = 0; p < PPL; p++) {
+		o[p] = t.y + tid * PPL + p;
+		active[p] = o[p] < npix;
+		const uint32_t oc = active[p] ? o[p] : npix - 1;
+		row[p] = oc / g.w;
+		x[p] = oc - row[p] * g.w;
+		const uint32_t y = g.h - 1 - row[p];
+		px[p] = (double)x[p] + x0c; // renderer_precise.rs:27-28,34,62
+		py[p] = (double)y + y0c;
+		rpx[p] = (float)x[p] + 0.5f; // pixel centre relative to (x0,y0)
+		rpy[p] = (float)y + 0.5f;
+		rpx2[p] = f2{rpx[p], rpx[p]};
+		rpy2[p] = f2{rpy[p], rpy[p]};
+	}
 
 	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
 	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
 	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
 	const uint32_t stride = g.w + 1;
 	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
-	for (uint32_t i = tid; i < n_delta; i += TPB)
+	for (uint32_t i = tid; i < n_delta; i += NT)
 		s_delta[i] = 0;
 
 	const float wh = (float)max(g.w, g.h);
 	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
 	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
-	double best = __builtin_huge_val(); // rtree_segments.rs:57
-	float ub = __builtin_inff();        // CULL: squared distance to the nearest sampled vertex so far
+	double best[PPL];
+	float ub[PPL]; // CULL: squared distance to the nearest sampled vertex so far
+#pragma unroll
+	for (int p = 0; p < PPL; p++) {
+		best[p] = __builtin_huge_val(); // rtree_segments.rs:57
+		ub[p] = __builtin_inff();
+	}
 	const uint32_t wv = tid >> 6, lane = tid & 63;
 
-	auto exact_lds = [&](uint32_t i) {
+	auto exact_lds = [&](int p, uint32_t i) {
 		const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
 		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
-		const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
-		best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
+		const double d2 = exact_dist_sq(px[p], py[p], vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
+		best[p] = d2 < best[p] ? d2 : best[p]; // rtree_segments.rs:60-62
 	};
 
 	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
@@ -575,8 +595,8 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict_
 		__syncthreads();
 
 		// ---- stage: exact endpoints, f32 filter records, coordinate bound, row crossings ----
-		for (uint32_t i = tid; i < FCHUNK; i += TPB) {
-			if (i >= cnt) { // pad to a multiple of 4 with records that can never win (F = 2e36)
+		for (uint32_t i = tid; i < FCHUNK; i += NT) {
+			if (i >= cnt) { // pad the chunk with records that can never win (F = 2e36)
 				s_vx[i] = 1.0e18f;
 				s_vy[i] = 1.0e18f;
 				s_dx[i] = 0.0f;
@@ -600,8 +620,8 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict_
 			s_dy[i] = (float)dy;
 			s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
 			const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
-			float mf = (float)m * 1.000001f;         // round up
-			mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
+			float mf = (float)m * 1.000001f;          // round up
+			mf = mf >= 0.0f ? mf : __builtin_inff();  // NaN -> inf ("no usable bound")
 			atomicMax(&s_mbits, __float_as_uint(mf)); // non-negative floats order like uints
 			// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
 			if (!(ABL & 1) && vy != wy) {
@@ -629,25 +649,35 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict_
 		bool use_list = false;
 		if (CULL && Mc < 4096.0f) {
 			// A segment is dropped only if its distance to every pixel of the wave's strip exceeds
-			// R, with R^2 >= min(UB, SAT^2) for every lane: UB = squared distance to some vertex
+			// R, with R^2 >= min(UB, SAT^2) for every pixel: UB = squared distance to some vertex
 			// (>= the true minimum, and that vertex's own segment is within R, so it stays), and
 			// SAT = 6.2 px (beyond 5.97 px outside / 2.02 px inside the byte is saturated whatever
 			// the minimum is: the reference's own +-8 px candidate rule, rtree_segments.rs:47-53).
 			use_list = true;
+			float r2 = 0.0f;
 			for (uint32_t j = 0; j < cnt; j += 8) { // every 8th start vertex
-				const float ddx = rpx - s_vx[j], ddy = rpy - s_vy[j];
-				const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
-				ub = d2 < ub ? d2 : ub;
+				const float svx = s_vx[j], svy = s_vy[j];
+#pragma unroll
+				for (int p = 0; p < PPL; p++) {
+					const float ddx = rpx[p] - svx, ddy = rpy[p] - svy;
+					const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
+					ub[p] = d2 < ub[p] ? d2 : ub[p];
+				}
 			}
-			float r2 = ub < 38.44f ? ub : 38.44f; // SAT^2 = 6.2^2
+#pragma unroll
+			for (int p = 0; p < PPL; p++) {
+				const float c = ub[p] < 38.44f ? ub[p] : 38.44f; // SAT^2 = 6.2^2
+				r2 = c > r2 ? c : r2;
+			}
 			for (int sh = 32; sh > 0; sh >>= 1) {
 				const float other = __shfl_xor(r2, sh);
 				r2 = other > r2 ? other : r2;
 			}
 			const float R2 = r2 * 1.01f + 0.02f; // covers the f32 rounding of UB and of the boxes (M < 4096)
 			const float delta = 4.0e-6f * Mc;
-			const uint32_t row_a = __builtin_amdgcn_readlane(row, 0), row_b = __builtin_amdgcn_readlane(row, 63);
-			const uint32_t x_a = __builtin_amdgcn_readlane(x, 0), x_b = __builtin_amdgcn_readlane(x, 63);
+			// the strip of pixels this wave owns (wave-uniform): first pixel of lane 0 .. last of lane 63
+			const uint32_t row_a = __builtin_amdgcn_readlane(row[0], 0), row_b = __builtin_amdgcn_readlane(row[PPL - 1], 63);
+			const uint32_t x_a = __builtin_amdgcn_readlane(x[0], 0), x_b = __builtin_amdgcn_readlane(x[PPL - 1], 63);
 			const float X0 = (row_a == row_b ? (float)x_a : 0.0f) + 0.5f;
 			const float X1 = (row_a == row_b ? (float)x_b : (float)(g.w - 1)) + 0.5f;
 			const float Y0 = (float)(g.h - 1 - row_b) + 0.5f, Y1 = (float)(g.h - 1 - row_a) + 0.5f;
@@ -703,7 +733,10 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict_
 		constexpr float GSLACK = 1.0f + 1.0f / 262144.0f + 1.0f / 4194304.0f; // >= (1 + 2^-18)(1 + 2^-23)
 		const uint32_t n8 = (n_list + GRP - 1) & ~(GRP - 1); // padded records (F = 2e36) never win
 		const uint32_t n_groups = n8 / GRP;
-		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu;
+		uint32_t k1[PPL], k2[PPL], k3[PPL];
+#pragma unroll
+		for (int p = 0; p < PPL; p++)
+			k1[p] = k2[p] = k3[p] = 0xFFFFFFFFu;
 		uint32_t gmask_v = ~GMASK;
 		asm volatile("" : "+v"(gmask_v)); // VGPR operand (one SGPR/literal per VOP3 on gfx9)
 		const float4 *q_vx = reinterpret_cast<const float4 *>(a_vx), *q_vy = reinterpret_cast<const float4 *>(a_vy);
@@ -714,108 +747,116 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_pk(const GlyphDesc *__restrict_
 			asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
 			return r;
 		};
-		auto quad = [&](uint32_t q, f2 &Fa, f2 &Fb) { // records 4q .. 4q+3
-			const float4 vx = q_vx[q], vy = q_vy[q], dx = q_dx[q], dy = q_dy[q], iv = q_inv[q];
-			Fa = pk_filter(rpx2, rpy2, f2{vx.x, vx.y}, f2{vy.x, vy.y}, f2{dx.x, dx.y}, f2{dy.x, dy.y}, f2{iv.x, iv.y});
-			Fb = pk_filter(rpx2, rpy2, f2{vx.z, vx.w}, f2{vy.z, vy.w}, f2{dx.z, dx.w}, f2{dy.z, dy.w}, f2{iv.z, iv.w});
-		};
 		for (uint32_t gi = 0; gi < ((ABL & 2) ? min(n_groups, 1u) : n_groups); gi++) {
-			f2 Fa, Fb, Fc, Fd;
-			quad(2 * gi, Fa, Fb);
-			quad(2 * gi + 1, Fc, Fd);
-			// F >= +0: unsigned order of the bits is float order; NaN bits sort above +inf
-			uint32_t m = umin3(__float_as_uint(Fa.x), __float_as_uint(Fa.y), __float_as_uint(Fb.x));
-			m = umin3(m, __float_as_uint(Fb.y), __float_as_uint(Fc.x));
-			m = umin3(m, __float_as_uint(Fc.y), __float_as_uint(Fd.x));
-			m = min(m, __float_as_uint(Fd.y));
-			uint32_t gkey;
-			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(gkey) : "v"(m), "v"(gmask_v), "s"(gi));
-			k3 = umed3(k2, k3, gkey); // sorted triple: clamp(key, k_{j-1}, k_j)
-			k2 = umed3(k1, k2, gkey);
-			k1 = min(k1, gkey);
+			const float4 vxa = q_vx[2 * gi], vya = q_vy[2 * gi], dxa = q_dx[2 * gi], dya = q_dy[2 * gi], iva = q_inv[2 * gi];
+			const float4 vxb = q_vx[2 * gi + 1], vyb = q_vy[2 * gi + 1], dxb = q_dx[2 * gi + 1], dyb = q_dy[2 * gi + 1],
+			             ivb = q_inv[2 * gi + 1];
+#pragma unroll
+			for (int p = 0; p < PPL; p++) {
+				const f2 Fa = pk_filter(rpx2[p], rpy2[p], f2{vxa.x, vxa.y}, f2{vya.x, vya.y}, f2{dxa.x, dxa.y}, f2{dya.x, dya.y}, f2{iva.x, iva.y});
+				const f2 Fb = pk_filter(rpx2[p], rpy2[p], f2{vxa.z, vxa.w}, f2{vya.z, vya.w}, f2{dxa.z, dxa.w}, f2{dya.z, dya.w}, f2{iva.z, iva.w});
+				const f2 Fc = pk_filter(rpx2[p], rpy2[p], f2{vxb.x, vxb.y}, f2{vyb.x, vyb.y}, f2{dxb.x, dxb.y}, f2{dyb.x, dyb.y}, f2{ivb.x, ivb.y});
+				const f2 Fd = pk_filter(rpx2[p], rpy2[p], f2{vxb.z, vxb.w}, f2{vyb.z, vyb.w}, f2{dxb.z, dxb.w}, f2{dyb.z, dyb.w}, f2{ivb.z, ivb.w});
+				// F >= +0: unsigned order of the bits is float order; NaN bits sort above +inf
+				uint32_t m = umin3(__float_as_uint(Fa.x), __float_as_uint(Fa.y), __float_as_uint(Fb.x));
+				m = umin3(m, __float_as_uint(Fb.y), __float_as_uint(Fc.x));
+				m = umin3(m, __float_as_uint(Fc.y), __float_as_uint(Fd.x));
+				m = min(m, __float_as_uint(Fd.y));
+				uint32_t gkey;
+				asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(gkey) : "v"(m), "v"(gmask_v), "s"(gi));
+				k3[p] = umed3(k2[p], k3[p], gkey); // sorted triple: clamp(key, k_{j-1}, k_j)
+				k2[p] = umed3(k1[p], k2[p], gkey);
+				k1[p] = min(k1[p], gkey);
+			}
 		}
 
 		if (!(ABL & 4) && n_list > 0) {
 			const float M = Mc;
 			const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
-			// U >= min over all segments of C: the best group's minimum is a real segment's F
-			const float f1 = __uint_as_float(k1 & ~GMASK) * GSLACK;
-			float U = f1 + filter_err(f1, M) + e64;
-			if (!sane || !(U >= 0.0f))
-				U = __builtin_inff();
-			auto excluded = [&](float fk) { // fk <= the true filter value <= fk * GSLACK
-				return fk - filter_err(fk * GSLACK, M) - e64 > U; // false for NaN / inf U
-			};
-			bool rescan = !sane; // keys are meaningless without a bound: evaluate everything
-			if (sane) {
-				// ---- level 2: inside every group whose minimum cannot be excluded, sorted top-4
-				// of (F | position) over its 8 members (lane-divergent LDS reads) ----
-				uint32_t q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu, q3 = 0xFFFFFFFFu, q4 = 0xFFFFFFFFu;
-				const bool g2 = n_groups >= 2 && !excluded(__uint_as_float(k2 & ~GMASK));
-				const bool g3 = n_groups >= 3 && !excluded(__uint_as_float(k3 & ~GMASK));
-				if (g3 && n_groups > 3)
-					rescan = true; // a 4th group (and more) may hold candidates too
-				for (uint32_t j = 0; j < 3; j++) {
-					const bool take = j == 0 || (j == 1 ? g2 : g3);
-					if (take && !rescan) {
-						const uint32_t gbase = ((j == 0 ? k1 : (j == 1 ? k2 : k3)) & GMASK) * GRP;
-						for (uint32_t mth = 0; mth < GRP; mth++) {
-							const uint32_t pos = gbase + mth;
-							const float F = sc_filter(rpx, rpy, a_vx[pos], a_vy[pos], a_dx[pos], a_dy[pos], a_inv[pos]);
-							const uint32_t key = (__float_as_uint(F) & ~31u) | (j * GRP + mth); // 5 position bits
-							q4 = umed3(q3, q4, key);
-							q3 = umed3(q2, q3, key);
-							q2 = umed3(q1, q2, key);
-							q1 = min(q1, key);
+#pragma unroll
+			for (int p = 0; p < PPL; p++) {
+				// U >= min over all segments of C: the best group's minimum is a real segment's F
+				const float f1 = __uint_as_float(k1[p] & ~GMASK) * GSLACK;
+				float U = f1 + filter_err(f1, M) + e64;
+				if (!sane || !(U >= 0.0f))
+					U = __builtin_inff();
+				auto excluded = [&](float fk) { // fk <= the true filter value <= fk * GSLACK
+					return fk - filter_err(fk * GSLACK, M) - e64 > U; // false for NaN / inf U
+				};
+				bool rescan = !sane; // keys are meaningless without a bound: evaluate everything
+				if (sane) {
+					// ---- level 2: inside every group whose minimum cannot be excluded, sorted top-4
+					// of (F | position) over its 8 members (lane-divergent LDS reads) ----
+					uint32_t q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu, q3 = 0xFFFFFFFFu, q4 = 0xFFFFFFFFu;
+					const bool g2 = n_groups >= 2 && !excluded(__uint_as_float(k2[p] & ~GMASK));
+					const bool g3 = n_groups >= 3 && !excluded(__uint_as_float(k3[p] & ~GMASK));
+					if (g3 && n_groups > 3)
+						rescan = true; // a 4th group (and more) may hold candidates too
+					for (uint32_t j = 0; j < 3; j++) {
+						const bool take = j == 0 || (j == 1 ? g2 : g3);
+						if (take && !rescan) {
+							const uint32_t gbase = ((j == 0 ? k1[p] : (j == 1 ? k2[p] : k3[p])) & GMASK) * GRP;
+							for (uint32_t mth = 0; mth < GRP; mth++) {
+								const uint32_t pos = gbase + mth;
+								const float F = sc_filter(rpx[p], rpy[p], a_vx[pos], a_vy[pos], a_dx[pos], a_dy[pos], a_inv[pos]);
+								const uint32_t key = (__float_as_uint(F) & ~31u) | (j * GRP + mth); // 5 position bits
+								q4 = umed3(q3, q4, key);
+								q3 = umed3(q2, q3, key);
+								q2 = umed3(q1, q2, key);
+								q1 = min(q1, key);
+							}
+						}
+					}
+					if (!rescan) {
+						auto seg_of = [&](uint32_t key) { // position in the scanned arrays -> chunk index
+							const uint32_t jj = (key & 31u) / GRP, mm = key & (GRP - 1);
+							const uint32_t pos = ((jj == 0 ? k1[p] : (jj == 1 ? k2[p] : k3[p])) & GMASK) * GRP + mm;
+							return use_list ? c_idx[CULL ? wv : 0][pos] : pos;
+						};
+						// q1 is the overall best filter value of a real segment (never a padded record)
+						exact_lds(p, seg_of(q1));
+						const bool s2 = !excluded(__uint_as_float(q2 & ~31u)), s3 = !excluded(__uint_as_float(q3 & ~31u));
+						const bool s4 = !excluded(__uint_as_float(q4 & ~31u));
+						if (q2 != 0xFFFFFFFFu && s2)
+							exact_lds(p, seg_of(q2));
+						if (q3 != 0xFFFFFFFFu && s3)
+							exact_lds(p, seg_of(q3));
+						if (q4 != 0xFFFFFFFFu && s4) {
+							exact_lds(p, seg_of(q4));
+							rescan = true; // four near-ties: more may hide behind them
 						}
 					}
 				}
-				if (!rescan) {
-					auto seg_of = [&](uint32_t key) { // position in the scanned arrays -> chunk index
-						const uint32_t jj = (key & 31u) / GRP, mm = key & (GRP - 1);
-						const uint32_t pos = ((jj == 0 ? k1 : (jj == 1 ? k2 : k3)) & GMASK) * GRP + mm;
-						return use_list ? c_idx[CULL ? wv : 0][pos] : pos;
-					};
-					// q1 is the overall best filter value of a real segment (never a padded record)
-					exact_lds(seg_of(q1));
-					const bool s2 = !excluded(__uint_as_float(q2 & ~31u)), s3 = !excluded(__uint_as_float(q3 & ~31u));
-					const bool s4 = !excluded(__uint_as_float(q4 & ~31u));
-					if (q2 != 0xFFFFFFFFu && s2)
-						exact_lds(seg_of(q2));
-					if (q3 != 0xFFFFFFFFu && s3)
-						exact_lds(seg_of(q3));
-					if (q4 != 0xFFFFFFFFu && s4) {
-						exact_lds(seg_of(q4));
-						rescan = true; // four near-ties: more may hide behind them
+				if (rescan) {
+					// Rescan against a threshold Tk with L(Tk) > U (L increasing above it): fixed-point
+					// iteration for the crossing, pushed up, then VERIFIED; if the check fails nothing
+					// is excluded (Tk = inf).
+					float Tk = U + e64;
+					for (int it = 0; it < 3; it++)
+						Tk = U + e64 + filter_err(Tk * GSLACK, M);
+					Tk = Tk * 1.001f + 1e-30f;
+					if (!(Tk - filter_err(Tk * GSLACK, M) - e64 > U))
+						Tk = __builtin_inff();
+					for (uint32_t j = 0; j < ((ABL & 8) ? 0u : n_list); j++) {
+						const float F = sc_filter(rpx[p], rpy[p], a_vx[j], a_vy[j], a_dx[j], a_dy[j], a_inv[j]);
+						if (!(F > Tk))
+							exact_lds(p, use_list ? c_idx[CULL ? wv : 0][j] : j);
 					}
-				}
-			}
-			if (rescan) {
-				// Rescan against a threshold Tk with L(Tk) > U (L increasing above it): fixed-point
-				// iteration for the crossing, pushed up, then VERIFIED; if the check fails nothing
-				// is excluded (Tk = inf).
-				float Tk = U + e64;
-				for (int it = 0; it < 3; it++)
-					Tk = U + e64 + filter_err(Tk * GSLACK, M);
-				Tk = Tk * 1.001f + 1e-30f;
-				if (!(Tk - filter_err(Tk * GSLACK, M) - e64 > U))
-					Tk = __builtin_inff();
-				for (uint32_t j = 0; j < ((ABL & 8) ? 0u : n_list); j++) {
-					const float F = sc_filter(rpx, rpy, a_vx[j], a_vy[j], a_dx[j], a_dy[j], a_inv[j]);
-					if (!(F > Tk))
-						exact_lds(use_list ? c_idx[CULL ? wv : 0][j] : j);
 				}
 			}
 		}
 	}
 
-	if (active) {
-		// winding number = prefix sum of the row's histogram up to this column
-		int wn = 0;
-		const int *drow = s_delta + (row - r_first) * stride;
-		for (uint32_t k = 0; k <= ((ABL & 16) ? 0u : x); k++)
-			wn += drow[k];
-		out[g.out_off + o] = quantise(best, wn != 0);
+#pragma unroll
+	for (int p = 0; p < PPL; p++) {
+		if (active[p]) {
+			// winding number = prefix sum of the row's histogram up to this column
+			int wn = 0;
+			const int *drow = s_delta + (row[p] - r_first) * stride;
+			for (uint32_t k = 0; k <= ((ABL & 16) ? 0u : x[p]); k++)
+				wn += drow[k];
+			out[g.out_off + o[p]] = quantise(best[p], wn != 0);
+		}
 	}
 }
 
@@ -838,9 +879,9 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const dim3 grid(n_tiles_in);
 	// kernel argument: tile count, top bit set = dispatch in list order (no per-XCD remap)
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
-#define VG_LAUNCH_PK(A, C)                                                                              \
-	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles, \
-	                   sx, sy, ex, ey, out)
+#define VG_LAUNCH_PK(A, C, P)                                                                            \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C, P>), grid, dim3(vgsdf::TPB / P), 0, stream, glyphs, tiles,  \
+	                   n_tiles, sx, sy, ex, ey, out)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
@@ -861,20 +902,24 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		default: VG_LAUNCH_FILTERED(0, true); break;
 		}
 	} else if (variant == 2) // packed filter, no culling
-		VG_LAUNCH_PK(0, false);
+		VG_LAUNCH_PK(0, false, 2);
+	else if (variant == 22) // packed filter, 1 pixel per lane, no culling (A/B)
+		VG_LAUNCH_PK(0, false, 1);
+	else if (variant == 23)
+		VG_LAUNCH_PK(0, true, 1);
 	else if (variant == 12) // previous generation: scalar filter, no culling (A/B)
 		VG_LAUNCH_FILTERED(0, false);
 	else if (variant == 10)
 		VG_LAUNCH_FILTERED(0, true);
 	else if (variant == 54)
-		VG_LAUNCH_PK(4, false);
+		VG_LAUNCH_PK(4, false, 2);
 	else if (variant == 55)
-		VG_LAUNCH_PK(36, false);
+		VG_LAUNCH_PK(4, false, 1);
 	else if (variant == 56)
-		VG_LAUNCH_PK(68, false);
+		VG_LAUNCH_PK(36, false, 2);
 	else if (variant == 57)
-		VG_LAUNCH_PK(100, false);
+		VG_LAUNCH_PK(36, false, 1);
 	else
-		VG_LAUNCH_PK(0, true);
+		VG_LAUNCH_PK(0, true, 2);
 	return (int)hipGetLastError();
 }
