@@ -364,9 +364,44 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			auto heavier = [&](const uint2 &a, const uint2 &c) {
 				return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
 			};
+			// Workgroups are dealt round-robin over the 8 XCDs (position p runs on XCD p % 8, each
+			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
+			// into one L2 only: glyphs (heaviest first) are dealt to the currently shortest of 8
+			// per-XCD queues, and the queues are interleaved position by position.
+			auto order = [&](uint2 *first, uint2 *last) {
+				std::stable_sort(first, last, heavier);
+				const size_t cnt = (size_t)(last - first);
+				if (cnt < 64)
+					return;
+				std::vector<std::vector<uint2>> q(8);
+				size_t i = 0;
+				while (i < cnt) {
+					size_t j = i;
+					while (j < cnt && first[j].x == first[i].x)
+						j++; // [i, j) = the tiles of one glyph (adjacent after the stable sort)
+					size_t best = 0;
+					for (size_t k = 1; k < 8; k++)
+						if (q[k].size() < q[best].size())
+							best = k;
+					q[best].insert(q[best].end(), first + i, first + j);
+					i = j;
+				}
+				size_t out_i = 0, taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+				while (out_i < cnt)
+					for (size_t k = 0; k < 8 && out_i < cnt; k++) {
+						// position out_i runs on XCD out_i % 8 == k as long as no queue ran dry
+						size_t src = k;
+						if (taken[src] >= q[src].size()) { // dry: borrow from the fullest queue
+							for (size_t m = 0; m < 8; m++)
+								if (q[m].size() - taken[m] > q[src].size() - taken[src])
+									src = m;
+						}
+						first[out_i++] = q[src][taken[src]++];
+					}
+			};
 			if (b->tile_order != 0) {
-				std::stable_sort(ht, ht + b->n_plain, heavier);
-				std::stable_sort(ht + b->n_plain, ht + b->n_main, heavier);
+				order(ht, ht + b->n_plain);
+				order(ht + b->n_plain, ht + b->n_main);
 			}
 		}
 		for (uint32_t g = 0; g < n; g++) {
