@@ -198,7 +198,8 @@ def main():
             "unit": "GB/s",
             "frac": alg_gbs / HBM_PEAK_GBS,
             "traffic": traffic_bytes(args.workload, args.variant),
-            "kernel": "sdf_tiles_filtered (dominant and only kernel of a step)" if args.variant == 0 else "sdf_tiles",
+            "kernel": ("sdf_tiles_pk<0,false,1> (small glyphs) / sdf_tiles_filtered<0,true> (large glyphs): the only "
+                       "kernels of a step" if args.variant == 0 else f"variant {args.variant}"),
             "kernel_ms_avg": kernel_s * 1e3,
             "alg_bytes_per_launch": st["alg_bytes"],
             "note": "the path is FP64-VALU bound by construction (~250 flop/byte); see roofline_valu",
