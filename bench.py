@@ -252,21 +252,27 @@ def main():
     # ---- end-to-end (fonts -> PBF bytes), reported beside the headline, never as `value` --
     if world == 1 and not args.no_e2e:
         r = vg.Renderer.new_precise(local_rank)
-        w = vg.DummyWriter()
-        mgr.render_glyphs(w, r)           # warm
-        w = vg.DummyWriter()
-        t0 = time.perf_counter()
-        mgr.render_glyphs(w, r)
-        e2e = time.perf_counter() - t0
-        tm = mgr.timings()
-        out["e2e"] = {"gpu_path_glyphs_per_s": tm["glyphs"] / e2e, "seconds": e2e,
-                      "phases_s": {k: tm[k] for k in ("tessellate_s", "device_s", "encode_s", "write_s")},
-                      "note": "parse->tessellate->H2D->kernel->D2H->PBF encode, PCIe inclusive"}
+        out["e2e"] = {"note": "parse -> outline -> (flatten) -> H2D -> kernels -> D2H -> PBF encode, PCIe inclusive, "
+                              "best of 5 warm runs; device_front_end = flattening/closing/scale/bbox on the GPU"}
+        for label, fe in (("device_front_end", True), ("host_tessellation", False)):
+            mgr.set_device_front_end(fe)
+            best = None
+            for _ in range(5):
+                w = vg.DummyWriter()
+                t0 = time.perf_counter()
+                mgr.render_glyphs(w, r)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            tm = mgr.timings()
+            out["e2e"][label] = {"glyphs_per_s": tm["glyphs"] / best, "seconds": best,
+                                 "phases_s": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
+        out["e2e"]["gpu_path_glyphs_per_s"] = out["e2e"]["device_front_end"]["glyphs_per_s"]
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             fonts = [O.Font(p) for p in paths]
             secs, ctr = O.render_all(fonts, fid, O.BRUTE, O.default_threads())
             out["e2e"]["cpu_port_glyphs_per_s"] = ctr["glyphs"] / secs
+            out["e2e"]["cpu_threads"] = O.default_threads()
             out["e2e"]["gpu_over_cpu"] = out["e2e"]["gpu_path_glyphs_per_s"] / out["e2e"]["cpu_port_glyphs_per_s"]
 
     print(json.dumps(out), flush=True)

@@ -56,6 +56,9 @@ void vg_renderer_free(vg_renderer *r);
 vg_manager *vg_manager_new(int parallel);
 void vg_manager_free(vg_manager *m);
 void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch);
+/* 1: flatten / close / scale / bbox on the GPU (device front-end of vgsdf.h; HIP renderer
+ * only), 0: on host threads.  Same bytes either way. */
+void vg_manager_set_device_front_end(vg_manager *m, int on);
 int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
 int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
 int vg_manager_add_path(vg_manager *m, const char *path); /* always fails: out of scope, see header */

@@ -112,6 +112,44 @@ int vgsdf_batch_time(vgsdf_ctx *ctx, vgsdf_dbatch *b, int iters, float *total_ms
  * alternative implementations for A/B measurements. */
 int vgsdf_set_variant(vgsdf_ctx *ctx, int variant);
 
+/*
+ * Device front-end: the host only records the OutlineBuilder callbacks of
+ * every glyph (f32 font units); flattening (ring_builder.rs:62-110, ring.rs:119-187), ring
+ * closing (ring.rs:53-63), scale / shift (renderer.rs:122-131), bbox + buffer
+ * (renderer.rs:64-91) and Rings::get_segments run on the GPU, bit-exact with the host path.
+ *   prepare : commands in -> per-glyph rects out (needed for the PBF metrics and to size the
+ *             output); leaves segments, descriptors and tiles resident on the device.
+ *   render  : SDF raster of the prepared batch; bitmaps of the glyphs with has_raster != 0
+ *             are packed back to back in glyph order (w*h bytes each).
+ */
+typedef struct {
+	float x1, y1;  /* quad control / first cubic control */
+	float x2, y2;  /* second cubic control */
+	float x, y;    /* end point */
+	uint32_t kind; /* 0 move_to, 1 line_to, 2 quad_to, 3 curve_to, 4 close */
+} vgsdf_outline_cmd;
+
+typedef struct {
+	uint32_t n_glyphs;
+	const uint32_t *cmd_off;       /* [n_glyphs+1] prefix sums */
+	const vgsdf_outline_cmd *cmds; /* [cmd_off[n_glyphs]] */
+	const double *scale;           /* [n_glyphs] GLYPH_SIZE / units_per_em (renderer.rs:107) */
+	const double *shift_x;         /* [n_glyphs] (advance - advance_float) / 2 (renderer.rs:130) */
+} vgsdf_outlines;
+
+typedef struct {
+	int32_t x0, y0;      /* RenderResult.x0 / y0 (incl. -3 buffer) */
+	uint32_t w, h;       /* RenderResult.width / height (incl. +6) */
+	uint32_t n_segments;
+	uint32_t has_raster; /* 0 => PbfGlyph::empty (no ring survived, or empty bbox) */
+} vgsdf_rect;
+
+int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
+                           uint64_t *n_segments);
+int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps);
+/* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */
+int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey);
+
 /* Raw device pointer of the resident output bitmaps (for zero-copy consumers on the same
  * device, e.g. a torch tensor wrapping it); valid until vgsdf_batch_free. */
 void *vgsdf_batch_device_output(const vgsdf_dbatch *b);

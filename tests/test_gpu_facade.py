@@ -27,9 +27,10 @@ def test_render_glyph_kats(vg, hip):
         assert ascii_art(g.bitmap) == art
 
 
-def render_all_files(vg, hip, name, paths, threads=0, blocks_per_batch=0):
+def render_all_files(vg, hip, name, paths, threads=0, blocks_per_batch=0, device_front_end=True):
     m = vg.FontManager(True)
     m.set_threads(threads, blocks_per_batch)
+    m.set_device_front_end(device_front_end)
     fid = m.add_font_with_name(name, paths)
     w = vg.DummyWriter()
     m.render_glyphs(w, hip)
@@ -46,21 +47,24 @@ def check_files(oracle, fid, w, paths, mode):
     assert not bad, bad
 
 
-def test_fira_pbf_bytes(vg, oracle, hip):
-    fid, w, m = render_all_files(vg, hip, "Fira Sans Regular", [FIRA])
+@pytest.mark.parametrize("fe", [True, False], ids=["device_front_end", "host_tessellation"])
+def test_fira_pbf_bytes(vg, oracle, hip, fe):
+    fid, w, m = render_all_files(vg, hip, "Fira Sans Regular", [FIRA], device_front_end=fe)
     for start, size in FIRA_PBF_SIZES.items():  # recurse.rs:341-367 sizes hold for real pixels too
         assert len(w.files[f"{fid}/{start}-{start + 255}.pbf"]) == size
     check_files(oracle, fid, w, [FIRA], oracle.PRECISE)
 
 
-def test_noto_regular_pbf_bytes(vg, oracle, hip):
-    fid, w, m = render_all_files(vg, hip, "Noto Sans Regular", [NOTO], blocks_per_batch=7)
+@pytest.mark.parametrize("fe", [True, False], ids=["device_front_end", "host_tessellation"])
+def test_noto_regular_pbf_bytes(vg, oracle, hip, fe):
+    fid, w, m = render_all_files(vg, hip, "Noto Sans Regular", [NOTO], blocks_per_batch=7, device_front_end=fe)
     check_files(oracle, fid, w, [NOTO], oracle.BRUTE)
 
 
-def test_noto_all_languages_pbf_bytes(vg, oracle, hip):
+@pytest.mark.parametrize("fe", [True, False], ids=["device_front_end", "host_tessellation"])
+def test_noto_all_languages_pbf_bytes(vg, oracle, hip, fe):
     # config 3: 20 files merged, 6480 code points, 45 non-empty blocks
-    fid, w, m = render_all_files(vg, hip, "Noto Sans Regular", noto_files())
+    fid, w, m = render_all_files(vg, hip, "Noto Sans Regular", noto_files(), device_front_end=fe)
     t = m.timings()
     assert (t["glyphs"], t["rasters"], t["pixels"], t["segments"]) == (6480, 6445, 3295280, 3956999)
     check_files(oracle, fid, w, noto_files(), oracle.BRUTE)
@@ -69,4 +73,5 @@ def test_noto_all_languages_pbf_bytes(vg, oracle, hip):
 def test_single_threaded_and_batched_agree(vg, hip):
     a = render_all_files(vg, hip, "Fira Sans Regular", [FIRA], threads=1, blocks_per_batch=1)[1].files
     b = render_all_files(vg, hip, "Fira Sans Regular", [FIRA], threads=4, blocks_per_batch=256)[1].files
-    assert a == b
+    c = render_all_files(vg, hip, "Fira Sans Regular", [FIRA], threads=3, blocks_per_batch=5, device_front_end=False)[1].files
+    assert a == b == c

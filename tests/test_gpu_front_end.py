@@ -1,0 +1,136 @@
+"""GPU: the device front-end (outline commands -> flattened rings -> scaled segments + rects,
+csrc/outline_kernels.hip) against the oracle, and the whole pipeline through it against the
+golden PBF hashes.  Commands are what ttf-parser's OutlineBuilder receives (taken from the
+oracle's TTF reader here; the product's own reader is pinned to it in test_host_vs_oracle)."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from conftest import FIRA, GOLDEN, NOTO, NOTO_DIR
+from test_golden_cpu import set_paths
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    c = vg.SdfContext(0)
+    yield c
+    c.close()
+
+
+def record(vg, font, cps):
+    """host half of render_glyph up to the outline callbacks (renderer.rs:104-116,130)"""
+    cmds, cmd_off, scale, shift, ids = [], [0], [], [], []
+    sc = 24.0 / font.units_per_em
+    for cp in cps:
+        gid = font.glyph_index(int(cp))
+        if gid is None:
+            continue
+        for (kind, x1, y1, x2, y2, x, y) in font.outline(gid):
+            cmds.append((x1, y1, x2, y2, x, y, kind))
+        adv = (font.hor_advance(gid) or 0) * sc * 0.95
+        a = np.floor(adv + 0.5)  # round half away (adv >= 0)
+        cmd_off.append(len(cmds))
+        scale.append(sc)
+        shift.append((a - adv) / 2.0)
+        ids.append(int(cp))
+    return (np.array(cmd_off, np.uint32), np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE), np.array(scale), np.array(shift), ids)
+
+
+@pytest.mark.parametrize("path", [FIRA, NOTO, NOTO_DIR / "Noto Sans Arabic - Regular.ttf",
+                                  NOTO_DIR / "Noto Sans Myanmar - Regular.ttf"], ids=lambda p: p.stem[:18])
+def test_segments_and_rects_match_oracle(oracle, vg, ctx, path):
+    font = oracle.Font(path)
+    cps = font.codepoints()
+    cmd_off, cmds, scale, shift, ids = record(vg, font, cps[cps <= 0xFFFF])
+    rects, out_bytes, n_segs = ctx.outlines_prepare(cmd_off, cmds, scale, shift)
+    seg_off, segs = ctx.outlines_segments()
+    assert len(rects) == len(ids)
+    tot_px = 0
+    for g, cp in enumerate(ids):
+        info, want = font.prepare_glyph(cp)
+        r = rects[g]
+        assert bool(r["has_raster"]) == bool(info.has_bitmap), cp
+        if not info.has_bitmap:
+            assert seg_off[g + 1] == seg_off[g]
+            continue
+        assert (int(r["x0"]), int(r["y0"]), int(r["w"]), int(r["h"]), int(r["n_segments"])) == \
+            (info.x0, info.y0, info.w, info.h, info.n_segments), cp
+        got = segs[seg_off[g]:seg_off[g + 1]]
+        assert got.tobytes() == want.tobytes(), f"segments differ for U+{cp:04X}"
+        tot_px += info.w * info.h
+    assert out_bytes == tot_px and n_segs == seg_off[-1]
+
+
+def test_bitmaps_through_front_end(oracle, vg, ctx, fira_oracle):
+    cmd_off, cmds, scale, shift, ids = record(vg, fira_oracle, range(0x20, 0x180))
+    rects, out_bytes, _ = ctx.outlines_prepare(cmd_off, cmds, scale, shift)
+    out = ctx.outlines_render()
+    off = 0
+    for g, cp in enumerate(ids):
+        info, bm = fira_oracle.render_glyph(cp, oracle.PRECISE)
+        if bm is None:
+            continue
+        n = bm.size
+        assert np.array_equal(out[off:off + n].reshape(bm.shape), bm), cp
+        off += n
+    assert off == out_bytes
+
+
+def test_arbitrary_command_streams(oracle, vg, ctx):
+    # streams ttf-parser never emits: curve_to, quad_to on an empty ring, line_to starting a
+    # ring, missing close, degenerate rings, repeated closes; rings via the oracle's RingBuilder
+    M, L, Q, C, Z = 0, 1, 2, 3, 4
+    streams = [
+        [(M, 0, 0, 0, 0, 100, 100), (C, 300, 500, 700, 500, 900, 100), (L, 0, 0, 0, 0, 500, -300), (Z,) + (0,) * 6],
+        [(Q, 10, 10, 0, 0, 20, 20), (L, 0, 0, 0, 0, 0, 0), (L, 0, 0, 0, 0, 400, 0), (Q, 600, 300, 0, 0, 400, 600),
+         (L, 0, 0, 0, 0, 0, 600)],  # no close: into_rings saves it
+        [(M, 0, 0, 0, 0, 0, 0), (L, 0, 0, 0, 0, 10, 0), (Z,) + (0,) * 6, (Z,) + (0,) * 6,
+         (M, 0, 0, 0, 0, 50, 50), (L, 0, 0, 0, 0, 450, 50), (L, 0, 0, 0, 0, 450, 450), (L, 0, 0, 0, 0, 50, 50), (Z,) + (0,) * 6],
+        [(M, 0, 0, 0, 0, 0, 0), (Z,) + (0,) * 6, (Q, 1, 1, 0, 0, 2, 2), (Q, 5, 5, 0, 0, 9, 9)],  # nothing survives
+        [],
+    ]
+    cmds, cmd_off = [], [0]
+    for st in streams:
+        for c in st:
+            c = tuple(c) + (0,) * (7 - len(c))
+            cmds.append((c[1], c[2], c[3], c[4], c[5], c[6], c[0]))
+        cmd_off.append(len(cmds))
+    scale = np.full(len(streams), 24.0 / 1000.0)
+    shift = np.array([0.0, 0.125, -0.25, 0.0, 0.0])
+    rects, _, _ = ctx.outlines_prepare(np.array(cmd_off, np.uint32), np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE), scale, shift)
+    seg_off, segs = ctx.outlines_segments()
+    for g, st in enumerate(streams):
+        rings = oracle.build_rings([tuple(c) + (0,) * (7 - len(c)) for c in st])
+        want = []
+        for r in rings:
+            p = r * scale[g]
+            p[:, 0] += shift[g]
+            p[:, 1] += 0.0
+            want.append(np.concatenate([p[:-1], p[1:]], axis=1))
+        want = np.concatenate(want) if want else np.zeros((0, 4))
+        got = segs[seg_off[g]:seg_off[g + 1]]
+        if len(want):
+            assert rects[g]["has_raster"] == 1 and got.tobytes() == want.tobytes(), g
+            allp = np.concatenate([want[:, :2], want[:, 2:]])
+            assert int(rects[g]["x0"]) == int(np.floor(allp[:, 0].min())) - 3
+            assert int(rects[g]["h"]) == int(np.ceil(allp[:, 1].max())) + 3 - (int(np.floor(allp[:, 1].min())) - 3)
+        else:
+            assert rects[g]["has_raster"] == 0 and len(got) == 0, g
+
+
+@pytest.mark.parametrize("name", ["fira", "noto_all"])
+def test_pbf_sha_with_device_front_end(vg, name):
+    disp, paths = set_paths(name)
+    m = vg.FontManager(True)
+    m.set_device_front_end(True)
+    fid = m.add_font_with_name(disp, paths)
+    w = vg.DummyWriter()
+    m.render_glyphs(w, vg.Renderer.new_precise(0))
+    want = json.loads((GOLDEN / "pbf_sha256.json").read_text())[name]
+    bad = [s for s, sha in want.items()
+           if hashlib.sha256(w.files[f"{fid}/{s}-{int(s) + 255}.pbf"]).hexdigest() != sha]
+    assert not bad, bad

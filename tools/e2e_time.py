@@ -8,8 +8,9 @@ vg = load_product()
 which = sys.argv[1] if len(sys.argv) > 1 else "noto_regular"
 paths = [NOTO] if which == "noto_regular" else noto_files()
 r = vg.Renderer.new_precise(0) if vg.device_count() else vg.Renderer.new_dummy()
-for th in (1, 4, 8, 16, 32):
-    m = vg.FontManager(True); m.set_threads(th, 0)
+fe = len(sys.argv) > 2 and sys.argv[2] == "fe"
+for th in (4, 16):
+    m = vg.FontManager(True); m.set_threads(th, 256 if fe else 0); m.set_device_front_end(fe)
     fid = m.add_font_with_name("Noto Sans Regular", paths)
     best = None
     for i in range(4):

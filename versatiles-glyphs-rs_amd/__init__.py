@@ -9,7 +9,7 @@ The directory name contains hyphens; load it by path (see tests/conftest.py:load
 """
 from .build import build, lib_path  # noqa: F401
 from .device import (  # noqa: F401
-    Batch, DeviceBatch, SdfContext, VgsdfError, device_count, make_batch, load_library,
+    Batch, DeviceBatch, OUTLINE_CMD_DTYPE, RECT_DTYPE, SdfContext, VgsdfError, device_count, make_batch, load_library,
 )
 from .host import (  # noqa: F401
     DummyWriter, FontManager, GlyphBatchHost, PbfGlyph, Renderer, name_to_id, pbf_encode,

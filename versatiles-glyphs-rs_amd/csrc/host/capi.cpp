@@ -63,6 +63,7 @@ void vg_renderer_free(vg_renderer *r) { delete r; }
 
 vg_manager *vg_manager_new(int parallel) { return new vg_manager(parallel != 0); }
 void vg_manager_free(vg_manager *m) { delete m; }
+void vg_manager_set_device_front_end(vg_manager *m, int on) { m->m.set_device_front_end(on != 0); }
 void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch)
 {
 	m->m.set_threads(threads);

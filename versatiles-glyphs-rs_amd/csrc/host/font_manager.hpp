@@ -117,6 +117,10 @@ public:
 	const RenderTimings &last_timings() const { return timings_; }
 	void set_threads(unsigned n) { threads_ = n; }
 	void set_batch_blocks(unsigned n) { batch_blocks_ = n ? n : 1; }
+	// true: flatten / close / scale / bbox on the GPU (device front-end, HIP renderer only);
+	// false: host tessellation.  Both produce identical bytes.
+	void set_device_front_end(bool on) { device_front_end_ = on; }
+	bool device_front_end() const { return device_front_end_; }
 
 private:
 	struct Todo {
@@ -133,12 +137,20 @@ private:
 		uint32_t g_raster = 0;             // first raster index in the packed batch
 		uint64_t g_seg = 0, g_out = 0;     // first segment / output byte in the packed batch
 	};
+	struct OSlice { // device front-end: a slice's glyph entries in its worker's OutlineBatch
+		uint32_t task = 0;
+		unsigned worker = 0;
+		uint32_t job0 = 0, job1 = 0;
+		uint32_t g_job = 0; // first glyph index in the merged batch
+	};
 	struct alignas(128) Worker { // own cache lines: the vector headers inside are written per glyph
 		TessScratch scratch;
 		GlyphBatch local;
+		OutlineBatch olocal;
 		char pad[128];
 	};
 	void run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
+	void run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
 	// tessellate tasks [t0, t1) on the pool and pack them (task order, ascending id) into `out`
 	void tessellate_and_pack(const std::vector<Todo> &tasks, size_t t0, size_t t1, std::vector<Slice> &slices,
 	                         PackedBatch &out);
@@ -147,10 +159,13 @@ private:
 	std::unique_ptr<ThreadPool> pool_;
 	std::vector<Worker> workers_;
 	PackedBatch packed_;
+	OutlineBatch omerged_;
+	HostBuffer<uint8_t> oout_{true};
+	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
 	bool parallel_;
 	unsigned threads_ = 0;       // 0 = hardware_concurrency
-	unsigned batch_blocks_ = 64; // blocks per GPU submission
+	unsigned batch_blocks_ = 256; // blocks per GPU submission (256 = one whole font)
 	RenderTimings timings_;
 };
 

@@ -221,6 +221,46 @@ bool Renderer::prepare(const Face &face, uint32_t index, TessScratch &scratch, G
 	return true;
 }
 
+bool Renderer::record(const Face &face, uint32_t index, OutlineBatch &batch)
+{
+	if (index > 0x10FFFF || (index >= 0xD800 && index <= 0xDFFF)) // renderer.rs:104
+		return false;
+	const auto glyph_id = face.glyph_index(index); // :106
+	if (!glyph_id)
+		return false;
+	const double scale = (double)GLYPH_SIZE / (double)face.units_per_em(); // :107
+	CommandRecorder rec(batch.cmds);
+	face.outline_glyph(*glyph_id, rec); // :109-111, callbacks only
+	const double advance_float = (double)face.glyph_hor_advance(*glyph_id).value_or(0) * scale * 0.95; // :115
+	const uint32_t advance = to_u32(std::round(advance_float));                                          // :116
+	GlyphJob job;
+	job.id = index;
+	job.advance = advance;
+	batch.jobs.push_back(job);
+	batch.cmd_off.push_back((uint32_t)batch.cmds.size());
+	batch.scale.push_back(scale);
+	batch.shift_x.push_back(((double)advance - advance_float) / 2.0); // :130
+	return true;
+}
+
+void Renderer::render_outlines(const OutlineBatch &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
+                               uint64_t &out_bytes, uint64_t &n_segments) const
+{
+	rects.assign(batch.jobs.size(), vgsdf_rect{});
+	out_bytes = n_segments = 0;
+	if (batch.jobs.empty())
+		return;
+	if (mode_ != Mode::Hip)
+		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
+	std::lock_guard<std::mutex> lock(mu_);
+	const vgsdf_outlines v = batch.view();
+	if (vgsdf_outlines_prepare(ctx_, &v, rects.data(), &out_bytes, &n_segments) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_outlines_prepare: ") + vgsdf_last_error(ctx_));
+	out.ensure((size_t)out_bytes + 1);
+	if (vgsdf_outlines_render(ctx_, out.data()) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(ctx_));
+}
+
 void Renderer::render_batch(const GlyphBatch &batch, uint8_t *out) const
 {
 	if (batch.n_raster() == 0)

@@ -142,6 +142,61 @@ struct PackedBatch {
 	vgsdf_batch view() const;
 };
 
+// Outline commands of a set of glyphs for the DEVICE front-end (vgsdf_outlines): the host
+// records what ttf-parser's OutlineBuilder receives; flattening, ring rules, scale/shift and
+// bbox then run on the GPU (csrc/outline_kernels.hip).
+struct OutlineBatch {
+	std::vector<GlyphJob> jobs;        // one per glyph the reference returns Some(..) for
+	std::vector<uint32_t> cmd_off{0};  // [jobs + 1]
+	std::vector<vgsdf_outline_cmd> cmds;
+	std::vector<double> scale, shift_x;
+
+	void clear()
+	{
+		jobs.clear();
+		cmd_off.assign(1, 0);
+		cmds.clear();
+		scale.clear();
+		shift_x.clear();
+	}
+	vgsdf_outlines view() const
+	{
+		vgsdf_outlines o;
+		o.n_glyphs = (uint32_t)jobs.size();
+		o.cmd_off = cmd_off.data();
+		o.cmds = cmds.data();
+		o.scale = scale.data();
+		o.shift_x = shift_x.data();
+		return o;
+	}
+};
+
+// OutlineBuilder sink that records the callbacks verbatim.
+class CommandRecorder final : public OutlineBuilder {
+public:
+	explicit CommandRecorder(std::vector<vgsdf_outline_cmd> &out) : out_(out) {}
+	void move_to(float x, float y) override { push(0, 0, 0, 0, 0, x, y); }
+	void line_to(float x, float y) override { push(1, 0, 0, 0, 0, x, y); }
+	void quad_to(float x1, float y1, float x, float y) override { push(2, x1, y1, 0, 0, x, y); }
+	void curve_to(float x1, float y1, float x2, float y2, float x, float y) override { push(3, x1, y1, x2, y2, x, y); }
+	void close() override { push(4, 0, 0, 0, 0, 0, 0); }
+
+private:
+	void push(uint32_t kind, float x1, float y1, float x2, float y2, float x, float y)
+	{
+		vgsdf_outline_cmd c;
+		c.x1 = x1;
+		c.y1 = y1;
+		c.x2 = x2;
+		c.y2 = y2;
+		c.x = x;
+		c.y = y;
+		c.kind = kind;
+		out_.push_back(c);
+	}
+	std::vector<vgsdf_outline_cmd> &out_;
+};
+
 // Per-thread scratch so tessellation allocates nothing in steady state.
 struct TessScratch {
 	RingBuilder builder;
@@ -164,6 +219,14 @@ public:
 	// sub-pixel shift, bbox + buffer.  nullopt = the reference returns None (glyph skipped).
 	// Rasterised glyphs get their segments appended to `batch`.
 	static bool prepare(const Face &face, uint32_t index, TessScratch &scratch, GlyphBatch &batch);
+
+	// Host half for the DEVICE front-end: cmap lookup, advance, scale / shift, and the raw
+	// outline commands (renderer.rs:104-116,130); everything else happens on the GPU.
+	static bool record(const Face &face, uint32_t index, OutlineBatch &batch);
+	// Device front-end + raster for a recorded batch: fills rects (one per job) and `out` with
+	// the bitmaps of the glyphs that have a raster, packed in job order.  Hip mode only.
+	void render_outlines(const OutlineBatch &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
+	                     uint64_t &out_bytes, uint64_t &n_segments) const;
 
 	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one
 	// vgsdf_render_batch call; Dummy: zeros (renderer_dummy.rs).  Throws std::runtime_error.

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/vgsdf.h"
+#include "outline_kernels.h"
 #include "sdf_kernels.h"
 
 namespace {
@@ -45,6 +46,7 @@ struct vgsdf_ctx {
 	// grow-only scratch of vgsdf_render_batch: no hipMalloc / hipHostMalloc in steady state
 	void *d_scratch = nullptr, *h_scratch = nullptr;
 	size_t d_scratch_bytes = 0, h_scratch_bytes = 0;
+	struct FrontEnd *fe = nullptr; // device outline front-end state (lazy)
 };
 
 struct vgsdf_dbatch {
@@ -64,6 +66,57 @@ struct vgsdf_dbatch {
 	int tile_order = 1;
 	bool borrowed = false; // arena + staging belong to the context (vgsdf_render_batch)
 };
+
+// grow-only device / pinned-host buffers of the outline front-end
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	bool host = false;
+	hipError_t ensure(size_t bytes)
+	{
+		if (bytes <= cap)
+			return hipSuccess;
+		release();
+		const size_t want = bytes + bytes / 4 + 256;
+		hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+		if (e != hipSuccess) {
+			p = nullptr;
+			return e;
+		}
+		cap = want;
+		return hipSuccess;
+	}
+	void release()
+	{
+		if (p)
+			(void)(host ? hipHostFree(p) : hipFree(p));
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+struct FrontEnd {
+	DevBuf cmds, cmd_off, scale, shift, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
+	DevBuf sx, sy, ex, ey, descs_tiles, out;
+	DevBuf h_rects, h_stage; // pinned
+	uint32_t n_glyphs = 0, n_cmds = 0, n_points = 0, n_segs = 0;
+	uint64_t out_bytes = 0;
+	vgsdf_dbatch batch; // borrowed view over the buffers above
+	bool prepared = false;
+	FrontEnd()
+	{
+		h_rects.host = true;
+		h_stage.host = true;
+		batch.borrowed = true;
+	}
+	void release_all()
+	{
+		for (DevBuf *b : {&cmds, &cmd_off, &scale, &shift, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
+		                  &seg_count, &seg_off, &scan_tmp, &sx, &sy, &ex, &ey, &descs_tiles, &out, &h_rects, &h_stage})
+			b->release();
+	}
+};
+
 
 #define HIP_TRY(ctx, expr)                                                                     \
 	do {                                                                                       \
@@ -133,6 +186,10 @@ void vgsdf_destroy(vgsdf_ctx *ctx)
 		(void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1)
 		(void)hipEventDestroy(ctx->ev1);
+	if (ctx->fe) {
+		ctx->fe->release_all();
+		delete ctx->fe;
+	}
 	if (ctx->d_scratch)
 		(void)hipFree(ctx->d_scratch);
 	if (ctx->h_scratch)
@@ -177,6 +234,109 @@ int vgsdf_batch_free(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	}
 	delete b;
 	return VGSDF_OK;
+}
+
+// Fills the glyph descriptors and the tile list (routing + order) of a batch.  `ht` must hold
+// stats.n_tiles entries.  Shared by the segment entry points and the outline front-end.
+static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, uint2 *ht, vgsdf_dbatch *b)
+{
+	const uint32_t n = in->n_glyphs;
+		// Tiles the filtered kernel can take come first; a glyph goes to the brute-force
+		// kernel when its winding histogram (rows touched by 256 consecutive pixels, times
+		// w+1 columns) would not fit in LDS, or its segment index needs more than 24 bits.
+		const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
+		auto wants_brute = [&](uint32_t g) {
+			const uint64_t w = in->w[g];
+			if (w == 0)
+				return false;
+			const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
+			return rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24);
+		};
+		// Culling (per-wave candidate lists) only pays when a wave's strip of 64 pixels plus the
+		// 6.2 px saturation margin covers well under half of the bitmap: large glyphs.  Small
+		// glyphs (every real font at 24 px/EM) take the straight broadcast loop.
+		auto wants_cull = [&](uint32_t g) {
+			const float w = (float)in->w[g], h = (float)in->h[g];
+			if (w <= 0.0f || h <= 0.0f)
+				return false;
+			const float strip_rows = (float)((63u + in->w[g]) / in->w[g] + 1u);
+			const float keep_y = std::min(1.0f, (strip_rows + 12.4f) / h);
+			const float keep_x = in->w[g] <= 64u ? 1.0f : std::min(1.0f, 76.4f / w);
+			return keep_x * keep_y < 0.40f;
+		};
+		uint64_t ti = 0;
+		for (int pass = 0; pass < 3; pass++) {
+			for (uint32_t g = 0; g < n; g++) {
+				const int cls = wants_brute(g) ? 2 : (wants_cull(g) ? 1 : 0);
+				if (cls != pass)
+					continue;
+				const uint32_t px = in->w[g] * in->h[g];
+				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
+					ht[ti++] = make_uint2(g, p);
+			}
+			if (pass == 0)
+				b->n_plain = (uint32_t)ti;
+			if (pass == 1)
+				b->n_main = (uint32_t)ti;
+		}
+		// Heaviest tiles first (cost of a tile ~ its glyph's segment count): the dispatcher
+		// hands workgroups out in list order, so the long ones start early and the tail is
+		// made of short ones.  VGSDF_TILE_ORDER=0 keeps glyph order (+ per-XCD contiguous remap).
+		{
+			const char *ord = std::getenv("VGSDF_TILE_ORDER");
+			b->tile_order = ord ? std::atoi(ord) : 1;
+			auto heavier = [&](const uint2 &a, const uint2 &c) {
+				return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
+			};
+			// Workgroups are dealt round-robin over the 8 XCDs (position p runs on XCD p % 8, each
+			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
+			// into one L2 only: glyphs (heaviest first) are dealt to the currently shortest of 8
+			// per-XCD queues, and the queues are interleaved position by position.
+			auto order = [&](uint2 *first, uint2 *last) {
+				std::stable_sort(first, last, heavier);
+				const size_t cnt = (size_t)(last - first);
+				if (cnt < 64)
+					return;
+				std::vector<std::vector<uint2>> q(8);
+				size_t i = 0;
+				while (i < cnt) {
+					size_t j = i;
+					while (j < cnt && first[j].x == first[i].x)
+						j++; // [i, j) = the tiles of one glyph (adjacent after the stable sort)
+					size_t best = 0;
+					for (size_t k = 1; k < 8; k++)
+						if (q[k].size() < q[best].size())
+							best = k;
+					q[best].insert(q[best].end(), first + i, first + j);
+					i = j;
+				}
+				size_t out_i = 0, taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+				while (out_i < cnt)
+					for (size_t k = 0; k < 8 && out_i < cnt; k++) {
+						// position out_i runs on XCD out_i % 8 == k as long as no queue ran dry
+						size_t src = k;
+						if (taken[src] >= q[src].size()) { // dry: borrow from the fullest queue
+							for (size_t m = 0; m < 8; m++)
+								if (q[m].size() - taken[m] > q[src].size() - taken[src])
+									src = m;
+						}
+						first[out_i++] = q[src][taken[src]++];
+					}
+			};
+			if (b->tile_order != 0) {
+				order(ht, ht + b->n_plain);
+				order(ht + b->n_plain, ht + b->n_main);
+			}
+		}
+		for (uint32_t g = 0; g < n; g++) {
+			hd[g].seg_off = in->seg_off[g];
+			hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
+			hd[g].x0 = in->x0[g];
+			hd[g].y0 = in->y0[g];
+			hd[g].w = in->w[g];
+			hd[g].h = in->h[g];
+			hd[g].out_off = in->out_off[g];
+		}
 }
 
 static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out, bool use_ctx_scratch)
@@ -317,102 +477,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	if (n) {
 		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
 		uint2 *ht = (uint2 *)(hs + off_tiles);
-		// Tiles the filtered kernel can take come first; a glyph goes to the brute-force
-		// kernel when its winding histogram (rows touched by 256 consecutive pixels, times
-		// w+1 columns) would not fit in LDS, or its segment index needs more than 24 bits.
-		const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
-		auto wants_brute = [&](uint32_t g) {
-			const uint64_t w = in->w[g];
-			if (w == 0)
-				return false;
-			const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
-			return rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24);
-		};
-		// Culling (per-wave candidate lists) only pays when a wave's strip of 64 pixels plus the
-		// 6.2 px saturation margin covers well under half of the bitmap: large glyphs.  Small
-		// glyphs (every real font at 24 px/EM) take the straight broadcast loop.
-		auto wants_cull = [&](uint32_t g) {
-			const float w = (float)in->w[g], h = (float)in->h[g];
-			if (w <= 0.0f || h <= 0.0f)
-				return false;
-			const float strip_rows = (float)((63u + in->w[g]) / in->w[g] + 1u);
-			const float keep_y = std::min(1.0f, (strip_rows + 12.4f) / h);
-			const float keep_x = in->w[g] <= 64u ? 1.0f : std::min(1.0f, 76.4f / w);
-			return keep_x * keep_y < 0.40f;
-		};
-		uint64_t ti = 0;
-		for (int pass = 0; pass < 3; pass++) {
-			for (uint32_t g = 0; g < n; g++) {
-				const int cls = wants_brute(g) ? 2 : (wants_cull(g) ? 1 : 0);
-				if (cls != pass)
-					continue;
-				const uint32_t px = in->w[g] * in->h[g];
-				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
-					ht[ti++] = make_uint2(g, p);
-			}
-			if (pass == 0)
-				b->n_plain = (uint32_t)ti;
-			if (pass == 1)
-				b->n_main = (uint32_t)ti;
-		}
-		// Heaviest tiles first (cost of a tile ~ its glyph's segment count): the dispatcher
-		// hands workgroups out in list order, so the long ones start early and the tail is
-		// made of short ones.  VGSDF_TILE_ORDER=0 keeps glyph order (+ per-XCD contiguous remap).
-		{
-			const char *ord = std::getenv("VGSDF_TILE_ORDER");
-			b->tile_order = ord ? std::atoi(ord) : 1;
-			auto heavier = [&](const uint2 &a, const uint2 &c) {
-				return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
-			};
-			// Workgroups are dealt round-robin over the 8 XCDs (position p runs on XCD p % 8, each
-			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
-			// into one L2 only: glyphs (heaviest first) are dealt to the currently shortest of 8
-			// per-XCD queues, and the queues are interleaved position by position.
-			auto order = [&](uint2 *first, uint2 *last) {
-				std::stable_sort(first, last, heavier);
-				const size_t cnt = (size_t)(last - first);
-				if (cnt < 64)
-					return;
-				std::vector<std::vector<uint2>> q(8);
-				size_t i = 0;
-				while (i < cnt) {
-					size_t j = i;
-					while (j < cnt && first[j].x == first[i].x)
-						j++; // [i, j) = the tiles of one glyph (adjacent after the stable sort)
-					size_t best = 0;
-					for (size_t k = 1; k < 8; k++)
-						if (q[k].size() < q[best].size())
-							best = k;
-					q[best].insert(q[best].end(), first + i, first + j);
-					i = j;
-				}
-				size_t out_i = 0, taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-				while (out_i < cnt)
-					for (size_t k = 0; k < 8 && out_i < cnt; k++) {
-						// position out_i runs on XCD out_i % 8 == k as long as no queue ran dry
-						size_t src = k;
-						if (taken[src] >= q[src].size()) { // dry: borrow from the fullest queue
-							for (size_t m = 0; m < 8; m++)
-								if (q[m].size() - taken[m] > q[src].size() - taken[src])
-									src = m;
-						}
-						first[out_i++] = q[src][taken[src]++];
-					}
-			};
-			if (b->tile_order != 0) {
-				order(ht, ht + b->n_plain);
-				order(ht + b->n_plain, ht + b->n_main);
-			}
-		}
-		for (uint32_t g = 0; g < n; g++) {
-			hd[g].seg_off = in->seg_off[g];
-			hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
-			hd[g].x0 = in->x0[g];
-			hd[g].y0 = in->y0[g];
-			hd[g].w = in->w[g];
-			hd[g].h = in->h[g];
-			hd[g].out_off = in->out_off[g];
-		}
+		build_descs_and_tiles(in, hd, ht, b);
 		if (n_seg && !direct) {
 			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
 			std::memcpy(hs + off_sy, in->seg_sy, sizeof(double) * n_seg);
@@ -557,6 +622,249 @@ int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitma
 		rc = vgsdf_batch_download(ctx, b, out_bitmaps);
 	vgsdf_batch_free(ctx, b);
 	return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// outline front-end: commands in, rects out (prepare); bitmaps out (render)
+// ---------------------------------------------------------------------------------------
+#define FE_TRY(expr)                                                                            \
+	do {                                                                                        \
+		hipError_t e__ = (expr);                                                                \
+		if (e__ != hipSuccess) {                                                                \
+			ctx->err = std::string("vgsdf_outlines: " #expr ": ") + hipGetErrorString(e__);     \
+			return e__ == hipErrorOutOfMemory ? VGSDF_E_OOM : VGSDF_E_HIP;                      \
+		}                                                                                       \
+	} while (0)
+#define FE_KERNEL(expr)                                                                         \
+	do {                                                                                        \
+		int e__ = (expr);                                                                       \
+		if (e__ != 0) {                                                                         \
+			ctx->err = std::string("vgsdf_outlines: " #expr ": ") + hipGetErrorString((hipError_t)e__); \
+			return VGSDF_E_HIP;                                                                 \
+		}                                                                                       \
+	} while (0)
+
+int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
+                           uint64_t *n_segments)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x || !rects_out))) {
+		ctx->err = "vgsdf_outlines_prepare: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	static_assert(sizeof(vgsdf_outline_cmd) == sizeof(vgsdf::OutlineCmd), "ABI struct mirrors the kernel struct");
+	static_assert(sizeof(vgsdf_rect) == sizeof(vgsdf::OutlineRect), "ABI struct mirrors the kernel struct");
+	const uint32_t n = in->n_glyphs;
+	if (n && in->cmd_off[0] != 0) {
+		ctx->err = "vgsdf_outlines_prepare: cmd_off[0] must be 0";
+		return VGSDF_E_ARG;
+	}
+	for (uint32_t g = 0; g < n; g++)
+		if (in->cmd_off[g + 1] < in->cmd_off[g]) {
+			ctx->err = "vgsdf_outlines_prepare: cmd_off not monotone";
+			return VGSDF_E_ARG;
+		}
+	const uint32_t n_cmds = n ? in->cmd_off[n] : 0;
+	if (n_cmds && !in->cmds) {
+		ctx->err = "vgsdf_outlines_prepare: NULL command array";
+		return VGSDF_E_ARG;
+	}
+	for (uint32_t c = 0; c < n_cmds; c++)
+		if (in->cmds[c].kind > 4u) {
+			ctx->err = "vgsdf_outlines_prepare: unknown command kind";
+			return VGSDF_E_ARG;
+		}
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->fe)
+		ctx->fe = new (std::nothrow) FrontEnd();
+	if (!ctx->fe) {
+		ctx->err = "vgsdf_outlines_prepare: out of host memory";
+		return VGSDF_E_OOM;
+	}
+	FrontEnd &fe = *ctx->fe;
+	fe.prepared = false;
+	fe.n_glyphs = n;
+	fe.n_cmds = n_cmds;
+	fe.n_points = fe.n_segs = 0;
+	fe.out_bytes = 0;
+	if (out_bytes)
+		*out_bytes = 0;
+	if (n_segments)
+		*n_segments = 0;
+	if (n == 0) {
+		fe.prepared = true;
+		fe.batch.stats = vgsdf_stats{};
+		return VGSDF_OK;
+	}
+	hipStream_t st = ctx->stream;
+	FE_TRY(fe.cmds.ensure(sizeof(vgsdf::OutlineCmd) * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.cmd_off.ensure(4 * (size_t)(n + 1)));
+	FE_TRY(fe.scale.ensure(8 * (size_t)n));
+	FE_TRY(fe.shift.ensure(8 * (size_t)n));
+	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
+	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.pt_off.ensure(4 * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.rings.ensure(sizeof(vgsdf::RingRec) * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.cmd_ring.ensure(4 * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.rects.ensure(sizeof(vgsdf::OutlineRect) * (size_t)n));
+	FE_TRY(fe.seg_count.ensure(4 * (size_t)(n + 1)));
+	FE_TRY(fe.seg_off.ensure(4 * (size_t)(n + 1)));
+	const size_t tmp = std::max(vgsdf_outline_scan_temp_bytes(n_cmds + 1), vgsdf_outline_scan_temp_bytes(n + 1));
+	FE_TRY(fe.scan_tmp.ensure(tmp));
+	FE_TRY(fe.h_rects.ensure(sizeof(vgsdf::OutlineRect) * (size_t)n + 16));
+
+	if (n_cmds)
+		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
+	FE_TRY(hipMemcpyAsync(fe.cmd_off.p, in->cmd_off, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+	FE_TRY(hipMemcpyAsync(fe.scale.p, in->scale, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+	FE_TRY(hipMemcpyAsync(fe.shift.p, in->shift_x, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+
+	auto *d_cmds = (const vgsdf::OutlineCmd *)fe.cmds.p;
+	FE_KERNEL(vgsdf_outline_context(d_cmds, (const uint32_t *)fe.cmd_off.p, n, (uint8_t *)fe.cmd_open.p, st));
+	FE_KERNEL(vgsdf_outline_count(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (uint32_t *)fe.counts.p, st));
+	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_off.p,
+	                             n_cmds + 1, st));
+	uint32_t *h_word = (uint32_t *)fe.h_rects.p; // pinned scratch for the read-backs
+	FE_TRY(hipMemcpyAsync(h_word, (const uint32_t *)fe.pt_off.p + n_cmds, 4, hipMemcpyDeviceToHost, st));
+	FE_TRY(hipStreamSynchronize(st));
+	const uint32_t n_points = h_word[0];
+	fe.n_points = n_points;
+
+	FE_TRY(fe.ptx.ensure(8 * (size_t)n_points + 8));
+	FE_TRY(fe.pty.ensure(8 * (size_t)n_points + 8));
+	// a ring of k points yields at most k segments: n_points bounds the segment count
+	FE_TRY(fe.sx.ensure(8 * (size_t)n_points + 8));
+	FE_TRY(fe.sy.ensure(8 * (size_t)n_points + 8));
+	FE_TRY(fe.ex.ensure(8 * (size_t)n_points + 8));
+	FE_TRY(fe.ey.ensure(8 * (size_t)n_points + 8));
+
+	FE_KERNEL(vgsdf_outline_emit(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (const uint32_t *)fe.pt_off.p,
+	                             (double *)fe.ptx.p, (double *)fe.pty.p, st));
+	FE_KERNEL(vgsdf_outline_rings(d_cmds, (const uint32_t *)fe.cmd_off.p, (const uint32_t *)fe.pt_off.p, (const double *)fe.ptx.p,
+	                              (const double *)fe.pty.p, (const double *)fe.scale.p, (const double *)fe.shift.p, n,
+	                              (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, (vgsdf::OutlineRect *)fe.rects.p,
+	                              (uint32_t *)fe.seg_count.p, st));
+	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.seg_count.p, (uint32_t *)fe.seg_off.p,
+	                             n + 1, st));
+	FE_KERNEL(vgsdf_outline_segments((const uint32_t *)fe.pt_off.p, n_cmds, n_points, (const uint32_t *)fe.cmd_ring.p,
+	                                 (const vgsdf::RingRec *)fe.rings.p, (const vgsdf::OutlineRect *)fe.rects.p,
+	                                 (const uint32_t *)fe.seg_off.p, (const double *)fe.ptx.p, (const double *)fe.pty.p,
+	                                 (const double *)fe.scale.p, (const double *)fe.shift.p, (double *)fe.sx.p, (double *)fe.sy.p,
+	                                 (double *)fe.ex.p, (double *)fe.ey.p, st));
+	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects.p, sizeof(vgsdf::OutlineRect) * (size_t)n, hipMemcpyDeviceToHost, st));
+	FE_TRY(hipStreamSynchronize(st));
+	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
+
+	// host: offsets, descriptors, tile list (same routing/order as the segment entry points)
+	std::vector<uint32_t> seg_off(n + 1, 0), w(n), h(n);
+	std::vector<int32_t> x0(n), y0(n);
+	std::vector<uint64_t> out_off(n + 1, 0);
+	uint64_t n_tiles = 0, n_pairs = 0;
+	for (uint32_t g = 0; g < n; g++) {
+		const vgsdf_rect &r = rects_out[g];
+		const uint64_t px = r.has_raster ? (uint64_t)r.w * r.h : 0;
+		if (px > 0xFFFFFFFFull - VGSDF_TILE_PIXELS) {
+			ctx->err = "vgsdf_outlines_prepare: glyph bitmap too large";
+			return VGSDF_E_ARG;
+		}
+		seg_off[g + 1] = seg_off[g] + (r.has_raster ? r.n_segments : 0);
+		x0[g] = r.x0;
+		y0[g] = r.y0;
+		w[g] = r.has_raster ? r.w : 0;
+		h[g] = r.has_raster ? r.h : 0;
+		out_off[g + 1] = out_off[g] + px;
+		n_tiles += (px + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
+		n_pairs += px * r.n_segments;
+	}
+	if (n_tiles > 0x7FFFFFFFull) {
+		ctx->err = "vgsdf_outlines_prepare: batch too large (tile count exceeds 2^31-1); split it";
+		return VGSDF_E_ARG;
+	}
+	fe.n_segs = seg_off[n];
+	fe.out_bytes = out_off[n];
+	vgsdf_batch view{};
+	view.n_glyphs = n;
+	view.seg_off = seg_off.data();
+	view.x0 = x0.data();
+	view.y0 = y0.data();
+	view.w = w.data();
+	view.h = h.data();
+	view.out_off = out_off.data();
+	vgsdf_dbatch &b = fe.batch;
+	b.stats.n_glyphs = n;
+	b.stats.n_segments = fe.n_segs;
+	b.stats.n_pixels = fe.out_bytes;
+	b.stats.n_pairs = n_pairs;
+	b.stats.n_tiles = n_tiles;
+	b.stats.alg_bytes = 32 * (uint64_t)fe.n_segs + 32 * (uint64_t)n + fe.out_bytes;
+	b.out_bytes = (size_t)fe.out_bytes;
+	const size_t desc_bytes = align_up(sizeof(vgsdf::GlyphDesc) * (size_t)n, 256);
+	const size_t stage_bytes = desc_bytes + sizeof(uint2) * (size_t)n_tiles;
+	FE_TRY(fe.h_stage.ensure(stage_bytes + 16));
+	FE_TRY(fe.descs_tiles.ensure(stage_bytes + 16));
+	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16));
+	auto *hd = (vgsdf::GlyphDesc *)fe.h_stage.p;
+	auto *ht = (uint2 *)((uint8_t *)fe.h_stage.p + desc_bytes);
+	build_descs_and_tiles(&view, hd, ht, &b);
+	FE_TRY(hipMemcpyAsync(fe.descs_tiles.p, fe.h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
+	b.d_glyphs = (vgsdf::GlyphDesc *)fe.descs_tiles.p;
+	b.d_tiles = (uint2 *)((uint8_t *)fe.descs_tiles.p + desc_bytes);
+	b.d_sx = (double *)fe.sx.p;
+	b.d_sy = (double *)fe.sy.p;
+	b.d_ex = (double *)fe.ex.p;
+	b.d_ey = (double *)fe.ey.p;
+	b.d_out = (uint8_t *)fe.out.p;
+	fe.prepared = true;
+	if (out_bytes)
+		*out_bytes = fe.out_bytes;
+	if (n_segments)
+		*n_segments = fe.n_segs;
+	return VGSDF_OK;
+}
+
+int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!ctx->fe || !ctx->fe->prepared) {
+		ctx->err = "vgsdf_outlines_render: call vgsdf_outlines_prepare first";
+		return VGSDF_E_ARG;
+	}
+	FrontEnd &fe = *ctx->fe;
+	if (fe.n_glyphs == 0 || fe.out_bytes == 0)
+		return VGSDF_OK;
+	if (!out_bitmaps) {
+		ctx->err = "vgsdf_outlines_render: NULL output";
+		return VGSDF_E_ARG;
+	}
+	int rc = vgsdf_batch_launch(ctx, &fe.batch);
+	if (rc != VGSDF_OK)
+		return rc;
+	return vgsdf_batch_download(ctx, &fe.batch, out_bitmaps);
+}
+
+int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey)
+{
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!ctx->fe || !ctx->fe->prepared) {
+		ctx->err = "vgsdf_outlines_segments: call vgsdf_outlines_prepare first";
+		return VGSDF_E_ARG;
+	}
+	FrontEnd &fe = *ctx->fe;
+	(void)hipSetDevice(ctx->device);
+	if (fe.n_glyphs && seg_off)
+		FE_TRY(hipMemcpyAsync(seg_off, fe.seg_off.p, 4 * (size_t)(fe.n_glyphs + 1), hipMemcpyDeviceToHost, ctx->stream));
+	const size_t nb = 8 * (size_t)fe.n_segs;
+	if (nb && sx && sy && ex && ey) {
+		FE_TRY(hipMemcpyAsync(sx, fe.sx.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+		FE_TRY(hipMemcpyAsync(sy, fe.sy.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+		FE_TRY(hipMemcpyAsync(ex, fe.ex.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+		FE_TRY(hipMemcpyAsync(ey, fe.ey.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+	}
+	FE_TRY(hipStreamSynchronize(ctx->stream));
+	return VGSDF_OK;
 }
 
 } // extern "C"

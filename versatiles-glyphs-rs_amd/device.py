@@ -26,11 +26,22 @@ class _CStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_glyphs", "n_segments", "n_pixels", "n_pairs", "n_tiles", "alg_bytes")]
 
 
+OUTLINE_CMD_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("x", "<f4"), ("y", "<f4"),
+                              ("kind", "<u4")])
+RECT_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("w", "<u4"), ("h", "<u4"), ("n_segments", "<u4"),
+                       ("has_raster", "<u4")])
+
+
+class _COutlines(C.Structure):
+    _fields_ = [("n_glyphs", C.c_uint32), ("cmd_off", C.c_void_p), ("cmds", C.c_void_p), ("scale", C.c_void_p),
+                ("shift_x", C.c_void_p)]
+
+
 VGSDF_SYMBOLS = [
     "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
-    "vgsdf_host_alloc", "vgsdf_host_free",
+    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_segments",
 ]
 
 _lib = None
@@ -67,6 +78,9 @@ def load_library():
         L.vgsdf_host_alloc.restype = vp
         L.vgsdf_host_free.argtypes = [vp]
         L.vgsdf_host_free.restype = None
+        L.vgsdf_outlines_prepare.argtypes = [vp, C.POINTER(_COutlines), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.vgsdf_outlines_render.argtypes = [vp, vp]
+        L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -200,6 +214,34 @@ class SdfContext:
         self._check(load_library().vgsdf_batch_upload(self._h, C.byref(cb), C.byref(h)))
         self.sync()
         return DeviceBatch(self, h, batch.out_bytes)
+
+    def outlines_prepare(self, cmd_off, cmds, scale, shift_x):
+        """device front-end, step 1: outline commands -> (rects, out_bytes, n_segments)"""
+        cmd_off = np.ascontiguousarray(cmd_off, dtype=np.uint32)
+        cmds = np.ascontiguousarray(cmds, dtype=OUTLINE_CMD_DTYPE)
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+        shift_x = np.ascontiguousarray(shift_x, dtype=np.float64)
+        n = len(scale)
+        rects = np.zeros(n, dtype=RECT_DTYPE)
+        ob, ns = C.c_uint64(0), C.c_uint64(0)
+        co = _COutlines(n, cmd_off.ctypes.data, cmds.ctypes.data, scale.ctypes.data, shift_x.ctypes.data)
+        self._check(load_library().vgsdf_outlines_prepare(self._h, C.byref(co), rects.ctypes.data, C.byref(ob), C.byref(ns)))
+        self._fe = (n, int(ob.value), int(ns.value))
+        return rects, int(ob.value), int(ns.value)
+
+    def outlines_render(self) -> np.ndarray:
+        """device front-end, step 2: bitmaps of the glyphs with a raster, packed in glyph order"""
+        out = np.empty(self._fe[1], dtype=np.uint8)
+        self._check(load_library().vgsdf_outlines_render(self._h, out.ctypes.data))
+        return out
+
+    def outlines_segments(self):
+        """the segments the device front-end produced -> (seg_off[n+1], segs[S,4])"""
+        n, _, ns = self._fe
+        seg_off = np.zeros(n + 1, dtype=np.uint32)
+        cols = [np.zeros(ns, dtype=np.float64) for _ in range(4)]
+        self._check(load_library().vgsdf_outlines_segments(self._h, seg_off.ctypes.data, *[c.ctypes.data for c in cols]))
+        return seg_off, np.stack(cols, axis=1) if ns else np.zeros((0, 4))
 
     def sync(self):
         self._check(load_library().vgsdf_sync(self._h))

@@ -37,7 +37,7 @@ WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8), C.
 
 VGFONT_SYMBOLS = [
     "vg_last_error", "vg_renderer_new", "vg_renderer_free", "vg_manager_new", "vg_manager_free",
-    "vg_manager_set_threads", "vg_manager_add_font_with_name", "vg_manager_add_font_data", "vg_manager_add_path",
+    "vg_manager_set_threads", "vg_manager_set_device_front_end", "vg_manager_add_font_with_name", "vg_manager_add_font_data", "vg_manager_add_path",
     "vg_name_to_id", "vg_manager_block_counts", "vg_manager_render_glyphs", "vg_manager_timings",
     "vg_manager_render_block", "vg_manager_render_blocks", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
     "vg_glyph_batch_free", "vg_pbf_encode",
@@ -59,6 +59,8 @@ def _L():
         L.vg_manager_new.argtypes = [C.c_int]
         L.vg_manager_free.argtypes = [vp]
         L.vg_manager_set_threads.argtypes = [vp, C.c_uint, C.c_uint]
+        L.vg_manager_set_device_front_end.argtypes = [vp, C.c_int]
+        L.vg_manager_set_device_front_end.restype = None
         L.vg_manager_add_font_with_name.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
         L.vg_manager_add_font_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
         L.vg_manager_add_path.argtypes = [vp, C.c_char_p]
@@ -186,6 +188,10 @@ class FontManager:
 
     def set_threads(self, threads: int = 0, blocks_per_batch: int = 0):
         _L().vg_manager_set_threads(self._h, threads, blocks_per_batch)
+
+    def set_device_front_end(self, on: bool):
+        """flatten / close / scale / bbox on the GPU instead of host threads (HIP renderer only)"""
+        _L().vg_manager_set_device_front_end(self._h, 1 if on else 0)
 
     def add_font_with_name(self, name: str, sources):
         paths = [str(Path(p)).encode() for p in sources]
