@@ -52,7 +52,7 @@ int main()
 				if (mode == 2) k<2><<<grid, 256>>>(d, iters, 1.0001f, 0.5f);
 				hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
 			}
-			double instr_per_wave = (double)iters * 32; // 32 VALU instrs per iteration in every mode
+			double instr_per_wave = (double)iters * (mode == 1 ? 16 : 32); // mode 1 issues 16 packed instrs (= 32 FMAs/lane)
 			double waves_per_simd = wg_per_cu; // 4 waves per WG over 4 SIMDs
 			double cyc = ms * 1e-3 * 2.4e9 / (instr_per_wave * waves_per_simd);
 			printf("waves/SIMD %d mode %d (%s): %.3f ms, %.2f cycles per wave-instr per SIMD @2.4GHz\n", wg_per_cu, mode,
