@@ -95,11 +95,20 @@ def main():
 
     import torch
     dist = None
+    # Rehearsal switches (single-GPU box): VG_DIST_BACKEND=gloo keeps the collectives on the CPU,
+    # VG_SHARE_GPU=1 lets several ranks use device 0.  The driver's multi-GPU run uses neither.
+    backend = os.environ.get("VG_DIST_BACKEND", "nccl")
+    if os.environ.get("VG_SHARE_GPU") == "1":
+        local_rank = 0
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     vg = load_product()
     if vg.device_count() <= local_rank:
@@ -145,10 +154,10 @@ def main():
 
     counters = [256, st["n_glyphs"], st["n_pixels"]]   # blocks, glyphs, pixels rendered per step by this rank
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        c = torch.tensor(counters, dtype=torch.int64, device="cuda")
+        c = torch.tensor(counters, dtype=torch.int64, device=coll_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)        # the only RCCL payload: 24 bytes
         counters = [int(v) for v in c.tolist()]
 
