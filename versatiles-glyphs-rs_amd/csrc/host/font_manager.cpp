@@ -369,10 +369,10 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 			n_jobs += s.job1 - s.job0;
 			n_cmds += l.cmd_off[s.job1] - l.cmd_off[s.job0];
 		}
-		OutlineBatch &m = omerged_;
+		MergedOutlines &m = omerged_;
 		m.jobs.resize(n_jobs);
 		m.cmd_off.resize((size_t)n_jobs + 1);
-		m.cmds.resize(n_cmds);
+		m.cmds.ensure((size_t)n_cmds + 1);
 		m.scale.resize(n_jobs);
 		m.shift_x.resize(n_jobs);
 		m.cmd_off[0] = 0;
@@ -395,7 +395,7 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		timings_.pack_s += t2 - t1;
 
 		uint64_t out_bytes = 0, n_segs = 0;
-		renderer.render_outlines(m, rects, oout_, out_bytes, n_segs);
+		renderer.render_outlines(m.view(), rects, oout_, out_bytes, n_segs);
 		const double t3 = now_s();
 		timings_.device_s += t3 - t2;
 

@@ -159,7 +159,7 @@ private:
 	std::unique_ptr<ThreadPool> pool_;
 	std::vector<Worker> workers_;
 	PackedBatch packed_;
-	OutlineBatch omerged_;
+	MergedOutlines omerged_;
 	HostBuffer<uint8_t> oout_{true};
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here

@@ -243,17 +243,16 @@ bool Renderer::record(const Face &face, uint32_t index, OutlineBatch &batch)
 	return true;
 }
 
-void Renderer::render_outlines(const OutlineBatch &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
+void Renderer::render_outlines(const vgsdf_outlines &v, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
                                uint64_t &out_bytes, uint64_t &n_segments) const
 {
-	rects.assign(batch.jobs.size(), vgsdf_rect{});
+	rects.assign(v.n_glyphs, vgsdf_rect{});
 	out_bytes = n_segments = 0;
-	if (batch.jobs.empty())
+	if (v.n_glyphs == 0)
 		return;
 	if (mode_ != Mode::Hip)
 		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
 	std::lock_guard<std::mutex> lock(mu_);
-	const vgsdf_outlines v = batch.view();
 	if (vgsdf_outlines_prepare(ctx_, &v, rects.data(), &out_bytes, &n_segments) != VGSDF_OK)
 		throw std::runtime_error(std::string("vgsdf_outlines_prepare: ") + vgsdf_last_error(ctx_));
 	out.ensure((size_t)out_bytes + 1);

@@ -171,6 +171,24 @@ struct OutlineBatch {
 	}
 };
 
+// The merged batch handed to the device: commands in page-locked memory (DMA without staging).
+struct MergedOutlines {
+	std::vector<GlyphJob> jobs;
+	std::vector<uint32_t> cmd_off{0};
+	HostBuffer<vgsdf_outline_cmd> cmds{true};
+	std::vector<double> scale, shift_x;
+	vgsdf_outlines view() const
+	{
+		vgsdf_outlines o;
+		o.n_glyphs = (uint32_t)jobs.size();
+		o.cmd_off = cmd_off.data();
+		o.cmds = cmds.data();
+		o.scale = scale.data();
+		o.shift_x = shift_x.data();
+		return o;
+	}
+};
+
 // OutlineBuilder sink that records the callbacks verbatim.
 class CommandRecorder final : public OutlineBuilder {
 public:
@@ -225,7 +243,7 @@ public:
 	static bool record(const Face &face, uint32_t index, OutlineBatch &batch);
 	// Device front-end + raster for a recorded batch: fills rects (one per job) and `out` with
 	// the bitmaps of the glyphs that have a raster, packed in job order.  Hip mode only.
-	void render_outlines(const OutlineBatch &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
+	void render_outlines(const vgsdf_outlines &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
 	                     uint64_t &out_bytes, uint64_t &n_segments) const;
 
 	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one

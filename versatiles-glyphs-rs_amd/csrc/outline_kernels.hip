@@ -27,7 +27,11 @@
 namespace vgsdf {
 
 constexpr double kTolSq = 0.01; // ring_builder.rs:62 `precision`, passed as tolerance_sq (:91,:108)
-constexpr int kMaxStack = 40;   // > depth of any finite i16/f32 outline (depth grows with log4 of the size)
+constexpr int kMaxStack = 18;   // the work list holds depth + 1 entries; flatness shrinks 4x per level, so depth 16
+                                // covers control polygons up to ~4e8 font units.  Deeper (non-finite / absurd
+                                // input, where the reference would never finish) is cut off: a curve emits at
+                                // most 65 536 points.  (A stack-free variant that re-derives each node from
+                                // the root measured slower: 160 vs 100 us per pass on Noto Sans Regular.)
 
 // Iterative de Casteljau, explicit LIFO stack, right half pushed first (ring.rs:119-144).
 // Calls emit(x, y) for every point appended to the ring, in order.  Returns the count.

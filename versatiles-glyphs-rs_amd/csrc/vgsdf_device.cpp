@@ -730,6 +730,10 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(hipStreamSynchronize(st));
 	const uint32_t n_points = h_word[0];
 	fe.n_points = n_points;
+	if (n_points > (1u << 28)) {
+		ctx->err = "vgsdf_outlines_prepare: outlines flatten to more than 2^28 points (non-finite or absurd control points?)";
+		return VGSDF_E_ARG;
+	}
 
 	FE_TRY(fe.ptx.ensure(8 * (size_t)n_points + 8));
 	FE_TRY(fe.pty.ensure(8 * (size_t)n_points + 8));
