@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -241,102 +242,95 @@ int vgsdf_batch_free(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, uint2 *ht, vgsdf_dbatch *b)
 {
 	const uint32_t n = in->n_glyphs;
-		// Tiles the filtered kernel can take come first; a glyph goes to the brute-force
-		// kernel when its winding histogram (rows touched by 256 consecutive pixels, times
-		// w+1 columns) would not fit in LDS, or its segment index needs more than 24 bits.
-		const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
-		auto wants_brute = [&](uint32_t g) {
-			const uint64_t w = in->w[g];
-			if (w == 0)
-				return false;
-			const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
-			return rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24);
-		};
-		// Culling (per-wave candidate lists) only pays when a wave's strip of 64 pixels plus the
-		// 6.2 px saturation margin covers well under half of the bitmap: large glyphs.  Small
-		// glyphs (every real font at 24 px/EM) take the straight broadcast loop.
-		auto wants_cull = [&](uint32_t g) {
-			const float w = (float)in->w[g], h = (float)in->h[g];
-			if (w <= 0.0f || h <= 0.0f)
-				return false;
-			const float strip_rows = (float)((63u + in->w[g]) / in->w[g] + 1u);
-			const float keep_y = std::min(1.0f, (strip_rows + 12.4f) / h);
-			const float keep_x = in->w[g] <= 64u ? 1.0f : std::min(1.0f, 76.4f / w);
-			return keep_x * keep_y < 0.40f;
-		};
-		uint64_t ti = 0;
-		for (int pass = 0; pass < 3; pass++) {
-			for (uint32_t g = 0; g < n; g++) {
-				const int cls = wants_brute(g) ? 2 : (wants_cull(g) ? 1 : 0);
-				if (cls != pass)
-					continue;
+	// Routing.  A glyph goes to the brute-force kernel when its winding histogram (rows touched
+	// by 256 consecutive pixels, times w+1 columns) would not fit in LDS, or its segment index
+	// needs more than 24 bits.  Culling (per-wave candidate lists) only pays when a wave's strip
+	// of 64 pixels plus the 6.2 px saturation margin covers well under half of the bitmap: large
+	// glyphs.  Small glyphs (every real font at 24 px/EM) take the straight broadcast loop.
+	const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
+	auto klass = [&](uint32_t g) -> int {
+		const uint64_t w = in->w[g], h = in->h[g];
+		if (w == 0 || h == 0)
+			return 0;
+		const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
+		if (rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24))
+			return 2;
+		const float strip_rows = (float)((63u + w) / w + 1u);
+		const float keep_y = std::min(1.0f, (strip_rows + 12.4f) / (float)h);
+		const float keep_x = w <= 64u ? 1.0f : std::min(1.0f, 76.4f / (float)w);
+		return keep_x * keep_y < 0.40f ? 1 : 0;
+	};
+	const char *ord = std::getenv("VGSDF_TILE_ORDER");
+	b->tile_order = ord ? std::atoi(ord) : 1;
+
+	// glyph indices per class, heaviest (most segments) first inside a class: the dispatcher
+	// hands workgroups out in list order, so the long ones start early and the tail is made of
+	// short ones.  VGSDF_TILE_ORDER=0 keeps glyph order (+ per-XCD contiguous remap in-kernel).
+	static thread_local std::vector<uint32_t> idx[3];
+	static thread_local std::vector<uint2> queue[8];
+	for (auto &v : idx)
+		v.clear();
+	for (uint32_t g = 0; g < n; g++)
+		if ((uint64_t)in->w[g] * in->h[g] > 0)
+			idx[klass(g)].push_back(g);
+	auto nseg = [&](uint32_t g) { return in->seg_off[g + 1] - in->seg_off[g]; };
+	uint64_t ti = 0;
+	for (int cls = 0; cls < 3; cls++) {
+		std::vector<uint32_t> &gl = idx[cls];
+		const uint64_t first = ti;
+		if (b->tile_order != 0 && cls < 2)
+			std::stable_sort(gl.begin(), gl.end(), [&](uint32_t a, uint32_t c) { return nseg(a) > nseg(c); });
+		uint64_t n_cls_tiles = 0;
+		for (uint32_t g : gl)
+			n_cls_tiles += ((uint64_t)in->w[g] * in->h[g] + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
+		if (b->tile_order != 0 && cls < 2 && n_cls_tiles >= 64) {
+			// Workgroups are dealt round-robin over the 8 XCDs (position p runs on XCD p % 8, each
+			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
+			// into one L2 only: glyphs are dealt to the currently shortest of 8 per-XCD queues, and
+			// the queues are interleaved position by position.
+			for (auto &q : queue)
+				q.clear();
+			for (uint32_t g : gl) {
+				size_t best = 0;
+				for (size_t k = 1; k < 8; k++)
+					if (queue[k].size() < queue[best].size())
+						best = k;
+				const uint32_t px = in->w[g] * in->h[g];
+				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
+					queue[best].push_back(make_uint2(g, p));
+			}
+			size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			const uint64_t last = first + n_cls_tiles;
+			while (ti < last)
+				for (size_t k = 0; k < 8 && ti < last; k++) {
+					size_t src = k; // position ti runs on XCD ti % 8 == k as long as no queue ran dry
+					if (taken[src] >= queue[src].size())
+						for (size_t m = 0; m < 8; m++) // dry: borrow from the fullest queue
+							if (queue[m].size() - taken[m] > queue[src].size() - taken[src])
+								src = m;
+					ht[ti++] = queue[src][taken[src]++];
+				}
+		} else {
+			for (uint32_t g : gl) {
 				const uint32_t px = in->w[g] * in->h[g];
 				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
 					ht[ti++] = make_uint2(g, p);
 			}
-			if (pass == 0)
-				b->n_plain = (uint32_t)ti;
-			if (pass == 1)
-				b->n_main = (uint32_t)ti;
 		}
-		// Heaviest tiles first (cost of a tile ~ its glyph's segment count): the dispatcher
-		// hands workgroups out in list order, so the long ones start early and the tail is
-		// made of short ones.  VGSDF_TILE_ORDER=0 keeps glyph order (+ per-XCD contiguous remap).
-		{
-			const char *ord = std::getenv("VGSDF_TILE_ORDER");
-			b->tile_order = ord ? std::atoi(ord) : 1;
-			auto heavier = [&](const uint2 &a, const uint2 &c) {
-				return in->seg_off[a.x + 1] - in->seg_off[a.x] > in->seg_off[c.x + 1] - in->seg_off[c.x];
-			};
-			// Workgroups are dealt round-robin over the 8 XCDs (position p runs on XCD p % 8, each
-			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
-			// into one L2 only: glyphs (heaviest first) are dealt to the currently shortest of 8
-			// per-XCD queues, and the queues are interleaved position by position.
-			auto order = [&](uint2 *first, uint2 *last) {
-				std::stable_sort(first, last, heavier);
-				const size_t cnt = (size_t)(last - first);
-				if (cnt < 64)
-					return;
-				std::vector<std::vector<uint2>> q(8);
-				size_t i = 0;
-				while (i < cnt) {
-					size_t j = i;
-					while (j < cnt && first[j].x == first[i].x)
-						j++; // [i, j) = the tiles of one glyph (adjacent after the stable sort)
-					size_t best = 0;
-					for (size_t k = 1; k < 8; k++)
-						if (q[k].size() < q[best].size())
-							best = k;
-					q[best].insert(q[best].end(), first + i, first + j);
-					i = j;
-				}
-				size_t out_i = 0, taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-				while (out_i < cnt)
-					for (size_t k = 0; k < 8 && out_i < cnt; k++) {
-						// position out_i runs on XCD out_i % 8 == k as long as no queue ran dry
-						size_t src = k;
-						if (taken[src] >= q[src].size()) { // dry: borrow from the fullest queue
-							for (size_t m = 0; m < 8; m++)
-								if (q[m].size() - taken[m] > q[src].size() - taken[src])
-									src = m;
-						}
-						first[out_i++] = q[src][taken[src]++];
-					}
-			};
-			if (b->tile_order != 0) {
-				order(ht, ht + b->n_plain);
-				order(ht + b->n_plain, ht + b->n_main);
-			}
-		}
-		for (uint32_t g = 0; g < n; g++) {
-			hd[g].seg_off = in->seg_off[g];
-			hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
-			hd[g].x0 = in->x0[g];
-			hd[g].y0 = in->y0[g];
-			hd[g].w = in->w[g];
-			hd[g].h = in->h[g];
-			hd[g].out_off = in->out_off[g];
-		}
+		if (cls == 0)
+			b->n_plain = (uint32_t)ti;
+		if (cls == 1)
+			b->n_main = (uint32_t)ti;
+	}
+	for (uint32_t g = 0; g < n; g++) {
+		hd[g].seg_off = in->seg_off[g];
+		hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
+		hd[g].x0 = in->x0[g];
+		hd[g].y0 = in->y0[g];
+		hd[g].w = in->w[g];
+		hd[g].h = in->h[g];
+		hd[g].out_off = in->out_off[g];
+	}
 }
 
 static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out, bool use_ctx_scratch)
@@ -644,9 +638,17 @@ int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitma
 		}                                                                                       \
 	} while (0)
 
+static double fe_now()
+{
+	return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
                            uint64_t *n_segments)
 {
+	static const bool trace = std::getenv("VGSDF_TRACE") != nullptr;
+	const double tr0 = fe_now();
+	double tr1 = 0, tr2 = 0, tr3 = 0;
 	if (!ctx)
 		return VGSDF_E_ARG;
 	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x || !rects_out))) {
@@ -697,6 +699,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		fe.batch.stats = vgsdf_stats{};
 		return VGSDF_OK;
 	}
+	tr1 = fe_now();
 	hipStream_t st = ctx->stream;
 	FE_TRY(fe.cmds.ensure(sizeof(vgsdf::OutlineCmd) * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.cmd_off.ensure(4 * (size_t)(n + 1)));
@@ -728,6 +731,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	uint32_t *h_word = (uint32_t *)fe.h_rects.p; // pinned scratch for the read-backs
 	FE_TRY(hipMemcpyAsync(h_word, (const uint32_t *)fe.pt_off.p + n_cmds, 4, hipMemcpyDeviceToHost, st));
 	FE_TRY(hipStreamSynchronize(st));
+	tr2 = fe_now();
 	const uint32_t n_points = h_word[0];
 	fe.n_points = n_points;
 	if (n_points > (1u << 28)) {
@@ -759,6 +763,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects.p, sizeof(vgsdf::OutlineRect) * (size_t)n, hipMemcpyDeviceToHost, st));
 	FE_TRY(hipStreamSynchronize(st));
 	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
+	tr3 = fe_now();
 
 	// host: offsets, descriptors, tile list (same routing/order as the segment entry points)
 	std::vector<uint32_t> seg_off(n + 1, 0), w(n), h(n);
@@ -824,6 +829,9 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		*out_bytes = fe.out_bytes;
 	if (n_segments)
 		*n_segments = fe.n_segs;
+	if (trace)
+		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, upload+count+scan+sync %.3f ms, emit..rects+sync %.3f ms, tiles+H2D %.3f ms\n",
+		             (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (tr3 - tr2) * 1e3, (fe_now() - tr3) * 1e3);
 	return VGSDF_OK;
 }
 
@@ -842,10 +850,15 @@ int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps)
 		ctx->err = "vgsdf_outlines_render: NULL output";
 		return VGSDF_E_ARG;
 	}
+	static const bool trace = std::getenv("VGSDF_TRACE") != nullptr;
+	const double t0 = fe_now();
 	int rc = vgsdf_batch_launch(ctx, &fe.batch);
 	if (rc != VGSDF_OK)
 		return rc;
-	return vgsdf_batch_download(ctx, &fe.batch, out_bitmaps);
+	rc = vgsdf_batch_download(ctx, &fe.batch, out_bitmaps);
+	if (trace)
+		std::fprintf(stderr, "[vgsdf] render: launch+D2H+sync %.3f ms\n", (fe_now() - t0) * 1e3);
+	return rc;
 }
 
 int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey)
