@@ -88,6 +88,14 @@ vg_glyph_batch *vg_manager_build_batch(vg_manager *m, const char *font_id);
 int vg_glyph_batch_view(const vg_glyph_batch *b, vgsdf_batch *view, const uint32_t **ids, uint32_t *n_jobs);
 void vg_glyph_batch_free(vg_glyph_batch *b);
 
+/* Host half of the DEVICE front-end for every glyph of a font id: the recorded outline
+ * commands + scale / shift per glyph, i.e. the argument of vgsdf_outlines_prepare.  ids[i] /
+ * advances[i] = code point / PBF advance of glyph i.  Valid until vg_outline_batch_free. */
+typedef struct vg_outline_batch vg_outline_batch;
+vg_outline_batch *vg_manager_record_outlines(const vg_manager *m, const char *font_id);
+int vg_outline_batch_view(const vg_outline_batch *b, vgsdf_outlines *view, const uint32_t **ids, const uint32_t **advances);
+void vg_outline_batch_free(vg_outline_batch *b);
+
 /* Hand-encoder of the glyphs PBF (src/protobuf/glyphs.rs:66-70) for already rendered
  * glyphs; bitmaps[i] may be NULL when !has_bitmap. Returns needed size. */
 long vg_pbf_encode(const char *name, const char *range, const vg_pbf_glyph *glyphs, const uint8_t *const *bitmaps,

@@ -74,3 +74,36 @@ def test_single_block_render_matches(vg, oracle):
     got = m.render_block(vg.Renderer.new_dummy(), fid, 7424)
     want, _, _ = oracle.render_block([oracle.Font(FIRA)], fid, 7424, oracle.DUMMY)
     assert got == want and len(got) == 7260
+
+
+def test_recorded_outlines_match_oracle(vg, oracle):
+    """host half of the device front-end: the recorded OutlineBuilder callbacks, scale, shift and
+    advance of every glyph equal the oracle's (all 20 merged Noto files + Fira)"""
+    for name, paths in (("Fira Sans Regular", [FIRA]), ("Noto Sans Regular", noto_files())):
+        m = vg.FontManager(False)
+        rec = m.record_outlines(m.add_font_with_name(name, paths))
+        fonts = [oracle.Font(p) for p in paths]
+        prov = {}
+        for fi, f in enumerate(fonts):
+            for cp in f.codepoints():
+                if cp <= 0xFFFF:
+                    prov.setdefault(int(cp), fi)
+        g = 0
+        for cp in sorted(prov):
+            f = fonts[prov[cp]]
+            gid = f.glyph_index(cp)
+            if gid is None:
+                continue
+            assert int(rec["ids"][g]) == cp
+            want = f.outline(gid)
+            got = rec["cmds"][rec["cmd_off"][g]:rec["cmd_off"][g + 1]]
+            assert len(got) == len(want), cp
+            for c, (kind, x1, y1, x2, y2, x, y) in zip(got, want):
+                assert (int(c["kind"]), float(c["x1"]), float(c["y1"]), float(c["x2"]), float(c["y2"]), float(c["x"]),
+                        float(c["y"])) == (kind, x1, y1, x2, y2, x, y), cp
+            sc = 24.0 / f.units_per_em
+            adv = (f.hor_advance(gid) or 0) * sc * 0.95
+            a = float(np.floor(adv + 0.5))
+            assert rec["scale"][g] == sc and rec["shift_x"][g] == (a - adv) / 2.0 and int(rec["advances"][g]) == int(a)
+            g += 1
+        assert g == len(rec["ids"])

@@ -21,6 +21,10 @@ struct vg_manager {
 	vg::FontManager m;
 	explicit vg_manager(bool p) : m(p) {}
 };
+struct vg_outline_batch {
+	vg::OutlineBatch b;
+	std::vector<uint32_t> ids, advances;
+};
 struct vg_glyph_batch {
 	vg::PackedBatch b;
 	std::vector<uint32_t> ids;
@@ -213,6 +217,37 @@ int vg_glyph_batch_view(const vg_glyph_batch *b, vgsdf_batch *view, const uint32
 	return 0;
 }
 void vg_glyph_batch_free(vg_glyph_batch *b) { delete b; }
+
+vg_outline_batch *vg_manager_record_outlines(const vg_manager *m, const char *font_id)
+{
+	try {
+		auto *b = new vg_outline_batch();
+		std::string err;
+		if (!m->m.record_outlines(font_id, b->b, &err)) {
+			delete b;
+			g_err = err;
+			return nullptr;
+		}
+		for (const vg::GlyphJob &j : b->b.jobs) {
+			b->ids.push_back(j.id);
+			b->advances.push_back(j.advance);
+		}
+		return b;
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+int vg_outline_batch_view(const vg_outline_batch *b, vgsdf_outlines *view, const uint32_t **ids, const uint32_t **advances)
+{
+	*view = b->b.view();
+	if (ids)
+		*ids = b->ids.data();
+	if (advances)
+		*advances = b->advances.data();
+	return 0;
+}
+void vg_outline_batch_free(vg_outline_batch *b) { delete b; }
 
 long vg_pbf_encode(const char *name, const char *range, const vg_pbf_glyph *glyphs, const uint8_t *const *bitmaps,
                    int n, uint8_t *out, size_t cap)

@@ -286,6 +286,22 @@ bool FontManager::build_batch(const std::string &font_id, PackedBatch &out, std:
 	return true;
 }
 
+bool FontManager::record_outlines(const std::string &font_id, OutlineBatch &out, std::string *err) const
+{
+	auto it = fonts_.find(font_id);
+	if (it == fonts_.end()) {
+		if (err)
+			*err = "unknown font id " + font_id;
+		return false;
+	}
+	out.clear();
+	for (const GlyphBlock &b : it->second.get_blocks())
+		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+			if (const FontFileEntry *f = b.glyphs[ci])
+				Renderer::record(f->face(), b.start_index + ci, out);
+	return true;
+}
+
 void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 {
 	// manager.rs:86-97: one task per (font, block); all 256 blocks per font

@@ -113,6 +113,10 @@ public:
 	bool build_batch(const std::string &font_id, PackedBatch &out, std::vector<uint32_t> &ids, uint32_t &n_jobs,
 	                 std::string *err);
 
+	// Host half of the device front-end for every glyph of one font (ascending code point,
+	// first provider wins): what vgsdf_outlines_prepare is fed.
+	bool record_outlines(const std::string &font_id, OutlineBatch &out, std::string *err) const;
+
 	const std::map<std::string, FontWrapper> &fonts() const { return fonts_; }
 	const RenderTimings &last_timings() const { return timings_; }
 	void set_threads(unsigned n) { threads_ = n; }

@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .device import Batch, VgsdfError, _CBatch, load_library
+from .device import OUTLINE_CMD_DTYPE, Batch, VgsdfError, _CBatch, _COutlines, load_library
 
 MODE_HIP, MODE_DUMMY = 0, 1
 
@@ -40,7 +40,7 @@ VGFONT_SYMBOLS = [
     "vg_manager_set_threads", "vg_manager_set_device_front_end", "vg_manager_add_font_with_name", "vg_manager_add_font_data", "vg_manager_add_path",
     "vg_name_to_id", "vg_manager_block_counts", "vg_manager_render_glyphs", "vg_manager_timings",
     "vg_manager_render_block", "vg_manager_render_blocks", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
-    "vg_glyph_batch_free", "vg_pbf_encode",
+    "vg_glyph_batch_free", "vg_manager_record_outlines", "vg_outline_batch_view", "vg_outline_batch_free", "vg_pbf_encode",
 ]
 
 _bound = False
@@ -77,6 +77,11 @@ def _L():
         L.vg_glyph_batch_view.argtypes = [vp, C.POINTER(_CBatch), C.POINTER(C.POINTER(C.c_uint32)),
                                           C.POINTER(C.c_uint32)]
         L.vg_glyph_batch_free.argtypes = [vp]
+        L.vg_manager_record_outlines.restype = vp
+        L.vg_manager_record_outlines.argtypes = [vp, C.c_char_p]
+        L.vg_outline_batch_view.argtypes = [vp, C.POINTER(_COutlines), C.POINTER(C.POINTER(C.c_uint32)),
+                                            C.POINTER(C.POINTER(C.c_uint32))]
+        L.vg_outline_batch_free.argtypes = [vp]
         L.vg_pbf_encode.restype = C.c_long
         L.vg_pbf_encode.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PbfGlyph), C.POINTER(C.c_void_p), C.c_int,
                                     vp, C.c_size_t]
@@ -258,6 +263,31 @@ class FontManager:
         if got != need:
             raise RuntimeError(_err())
         return out.tobytes()
+
+    def record_outlines(self, font_id: str) -> dict:
+        """host half of the device front-end: {cmd_off, cmds, scale, shift_x, ids, advances} (numpy copies)"""
+        h = _L().vg_manager_record_outlines(self._h, font_id.encode())
+        if not h:
+            raise RuntimeError(_err())
+        try:
+            co = _COutlines()
+            ids, adv = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+            _L().vg_outline_batch_view(h, C.byref(co), C.byref(ids), C.byref(adv))
+            n = co.n_glyphs
+
+            def arr(ptr, count, dt):
+                if count == 0 or not ptr:
+                    return np.zeros(0, dtype=dt)
+                buf = (C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr)
+                return np.frombuffer(buf, dtype=dt, count=count).copy()
+
+            cmd_off = arr(co.cmd_off, n + 1, np.uint32)
+            return {"cmd_off": cmd_off, "cmds": arr(co.cmds, int(cmd_off[-1]) if n else 0, OUTLINE_CMD_DTYPE),
+                    "scale": arr(co.scale, n, np.float64), "shift_x": arr(co.shift_x, n, np.float64),
+                    "ids": arr(C.cast(ids, C.c_void_p).value, n, np.uint32),
+                    "advances": arr(C.cast(adv, C.c_void_p).value, n, np.uint32)}
+        finally:
+            _L().vg_outline_batch_free(h)
 
     def build_batch(self, font_id: str) -> GlyphBatchHost:
         h = _L().vg_manager_build_batch(self._h, font_id.encode())
