@@ -860,6 +860,309 @@ __global__ __launch_bounds__(TPB / PPL) void sdf_tiles_pk(const GlyphDesc *__res
 	}
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 30: bounded groups — the reference's "ask the R-tree for the segments near this pixel"
+// (rtree_segments.rs:40-56) done the wave64 way.  Same staging, winding and exact evaluation as
+// above; what changes is which (pixel, segment) pairs the f32 filter looks at.
+//
+//   bound   every run of GRP = 8 consecutive segments of the chunk (neighbours on the outline,
+//           so a run is ~1 px long) gets an anchor a_g (the start vertex of its middle segment)
+//           and a radius r_g >= |q - a_g| for every point q of the run.
+//   phase 1 a lane evaluates D_g = |p - a_g| for the <= 32 groups of the chunk (4 VALU ops each,
+//           broadcast LDS reads), keeps U = min D_g (an upper bound of the true minimum: a_g is
+//           on the outline) and marks group g as a candidate iff D_g - r_g <= min(U, SAT): a
+//           32-bit mask per lane.  A segment of a non-candidate group is farther than the true
+//           minimum (triangle inequality), or farther than SAT = 6.2 px where the byte is
+//           saturated anyway (same argument as the per-wave cull).
+//   phase 2 the lane walks ITS OWN candidate groups (lane-divergent LDS reads; ~3.5 groups on
+//           Noto Sans instead of 60) with the scalar filter and the sorted top-4 of (F | index),
+//           then the exact evaluation / rescan exactly as in sdf_tiles_filtered.
+// All f32 roundings of phase 1 are covered by inflating U and r_g by (1 + 2^-9) and an absolute
+// pad of 0.01 + 1e-5 M px (anchor and record end points are within 8 u M < 2e-3 px of the true
+// ones for M < 4096; D_g^2 has relative error < 2^-21).  For M >= 4096 every group is a candidate.
+// ---------------------------------------------------------------------------------------
+template <int ABL>
+__global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restrict__ glyphs,
+                                                      const uint2 *__restrict__ tiles, uint32_t n_tiles,
+                                                      const double *__restrict__ seg_sx,
+                                                      const double *__restrict__ seg_sy,
+                                                      const double *__restrict__ seg_ex,
+                                                      const double *__restrict__ seg_ey,
+                                                      uint8_t *__restrict__ out)
+{
+	constexpr uint32_t GRP = 8, NGRP = FCHUNK / GRP; // 32 groups per chunk: one mask bit each
+	static_assert(NGRP == 32 && TPB == FCHUNK, "one candidate bit per group, one staging thread per record");
+	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
+	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
+	__shared__ int s_delta[DELTA_CAP];
+	__shared__ uint32_t s_mbits;
+	__shared__ __attribute__((aligned(16))) float s_gx[NGRP], s_gy[NGRP], s_gr[NGRP]; // anchor, radius
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
+	const uint2 t = tiles[tile];
+	const GlyphDesc g = glyphs[t.x];
+	const uint32_t npix = g.w * g.h;
+	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
+	const uint32_t o = t.y + tid;
+	const bool active = o < npix;
+	const uint32_t oc = active ? o : npix - 1;
+	const uint32_t row = oc / g.w;
+	const uint32_t x = oc - row * g.w;
+	const uint32_t y = g.h - 1 - row;
+	const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
+	const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
+
+	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
+	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
+	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
+	const uint32_t stride = g.w + 1;
+	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
+	for (uint32_t i = tid; i < n_delta; i += TPB)
+		s_delta[i] = 0;
+
+	const float wh = (float)max(g.w, g.h);
+	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
+	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
+	double best = __builtin_huge_val(); // rtree_segments.rs:57
+	float ub2 = __builtin_inff();       // squared distance to the nearest anchor / exact candidate so far
+
+	auto exact_lds = [&](uint32_t i) {
+		const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
+		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
+		const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
+		best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
+	};
+
+	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
+		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
+		__syncthreads(); // previous chunk fully consumed (and s_delta zeroed on the first trip)
+		if (tid == 0)
+			s_mbits = __float_as_uint(wh);
+		__syncthreads();
+
+		// ---- stage (thread i <-> record i): exact endpoints, f32 record, coordinate bound, crossings ----
+		{
+			const uint32_t i = tid;
+			float mf = 0.0f;
+			if (i >= cnt) { // pad the chunk with records that can never win (F = 2e36)
+				s_vx[i] = 1.0e18f;
+				s_vy[i] = 1.0e18f;
+				s_dx[i] = 0.0f;
+				s_dy[i] = 0.0f;
+				s_inv[i] = 0.0f;
+			} else {
+				const uint32_t s = g.seg_off + c0 + i;
+				const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
+				e_vx[i] = vx;
+				e_vy[i] = vy;
+				e_wx[i] = wx;
+				e_wy[i] = wy;
+				const double dx = wx - vx, dy = wy - vy;
+				const double l2 = dx * dx + dy * dy;
+				const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
+				const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
+				s_vx[i] = (float)rvx;
+				s_vy[i] = (float)rvy;
+				s_dx[i] = (float)dx;
+				s_dy[i] = (float)dy;
+				s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
+				const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
+				mf = (float)m * 1.000001f;               // round up
+				mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
+				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
+				if (!(ABL & 1) && vy != wy) {
+					const bool up = vy < wy;
+					const double lo = up ? vy : wy, hi = up ? wy : vy;
+					const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
+					const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
+					for (int yy = ya; yy < yb; yy++) {
+						const double pyy = (double)yy + y0c;
+						const double tc = (pyy - vy) / dy;
+						const double xc = vx + tc * dx;               // :45-46 / :48-49
+						const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
+						if (k < (int)g.w)
+							atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
+					}
+				}
+			}
+			// coordinate bound: wave maximum first, one LDS atomic per wave (non-negative floats order like uints)
+			uint32_t mb = __float_as_uint(mf);
+			for (int sh = 32; sh > 0; sh >>= 1)
+				mb = max(mb, (uint32_t)__shfl_xor((int)mb, sh));
+			if ((tid & 63) == 0)
+				atomicMax(&s_mbits, mb);
+		}
+		__syncthreads();
+		const float Mc = __uint_as_float(s_mbits);
+		const bool sane = Mc < 1.0e6f;   // else: no usable f32 bound -> every segment is evaluated exactly
+		const bool bounded = Mc < 4096.0f; // group bounds have a useful margin
+		const float pad = 0.01f + 1.0e-5f * Mc;
+		constexpr float INFL = 1.0f + 1.0f / 512.0f;
+		const uint32_t n_groups = (cnt + GRP - 1) / GRP;
+
+		// ---- group bounds: anchor = start vertex of the middle member, radius over all end points ----
+		{
+			const uint32_t gb = tid & ~(GRP - 1);
+			const uint32_t ai = min(gb + GRP / 2, cnt - 1);
+			const float ax = s_vx[ai], ay = s_vy[ai];
+			float r2 = 0.0f;
+			if (tid < cnt) {
+				const float vx = s_vx[tid], vy = s_vy[tid];
+				const float wx = vx + s_dx[tid], wy = vy + s_dy[tid];
+				const float ex = vx - ax, ey = vy - ay, fx = wx - ax, fy = wy - ay;
+				const float dv = __builtin_fmaf(ey, ey, ex * ex), dw = __builtin_fmaf(fy, fy, fx * fx);
+				r2 = dv > dw ? dv : dw;
+			}
+			for (int sh = 1; sh < (int)GRP; sh <<= 1) {
+				const float other = __shfl_xor(r2, sh);
+				r2 = other > r2 ? other : r2;
+			}
+			if ((tid & (GRP - 1)) == 0) {
+				const bool empty = gb >= cnt;
+				s_gx[tid / GRP] = empty ? 1.0e18f : ax;
+				s_gy[tid / GRP] = empty ? 1.0e18f : ay;
+				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL;
+			}
+		}
+		__syncthreads();
+
+		// ---- phase 1: candidate groups of this lane ----
+		uint32_t cand = n_groups >= 32 ? 0xFFFFFFFFu : ((1u << n_groups) - 1u);
+		if (bounded && !(ABL & 32)) {
+			float D2[NGRP];
+			uint32_t dmin = __float_as_uint(ub2);
+			const float4 *gx4 = reinterpret_cast<const float4 *>(s_gx), *gy4 = reinterpret_cast<const float4 *>(s_gy);
+			const float4 *gr4 = reinterpret_cast<const float4 *>(s_gr);
+#pragma unroll
+			for (uint32_t b = 0; b < NGRP / 4; b++) {
+				if (b * 4 < n_groups) {
+					const float4 ax = gx4[b], ay = gy4[b];
+					const float axs[4] = {ax.x, ax.y, ax.z, ax.w}, ays[4] = {ay.x, ay.y, ay.z, ay.w};
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const float ddx = rpx - axs[j], ddy = rpy - ays[j];
+						const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
+						D2[b * 4 + j] = d2;
+						dmin = min(dmin, __float_as_uint(d2)); // d2 >= +0: unsigned order is float order
+					}
+				} else {
+#pragma unroll
+					for (int j = 0; j < 4; j++)
+						D2[b * 4 + j] = __builtin_inff();
+				}
+			}
+			ub2 = __uint_as_float(dmin);
+			float U = (__builtin_sqrtf(ub2) * INFL + pad) * INFL;
+			U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
+			cand = 0;
+#pragma unroll
+			for (uint32_t b = 0; b < NGRP / 4; b++) {
+				if (b * 4 < n_groups) {
+					const float4 r = gr4[b];
+					const float rs[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const float tt = U + rs[j];
+						cand |= (D2[b * 4 + j] <= tt * tt) ? (1u << (b * 4 + j)) : 0u;
+					}
+				}
+			}
+		}
+
+		// ---- phase 2: f32 filter over the lane's candidate groups, sorted top-4 of (F | index) ----
+		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
+		const float4 *q_vx = reinterpret_cast<const float4 *>(s_vx), *q_vy = reinterpret_cast<const float4 *>(s_vy);
+		const float4 *q_dx = reinterpret_cast<const float4 *>(s_dx), *q_dy = reinterpret_cast<const float4 *>(s_dy);
+		const float4 *q_inv = reinterpret_cast<const float4 *>(s_inv);
+		if (sane && !(ABL & 2)) {
+			uint32_t m = cand;
+			while (m) {
+				const uint32_t gq = (uint32_t)__builtin_ctz(m);
+				m &= m - 1;
+				const float4 vxa = q_vx[2 * gq], vya = q_vy[2 * gq], dxa = q_dx[2 * gq], dya = q_dy[2 * gq], iva = q_inv[2 * gq];
+				const float4 vxb = q_vx[2 * gq + 1], vyb = q_vy[2 * gq + 1], dxb = q_dx[2 * gq + 1], dyb = q_dy[2 * gq + 1],
+				             ivb = q_inv[2 * gq + 1];
+				const float vxs[8] = {vxa.x, vxa.y, vxa.z, vxa.w, vxb.x, vxb.y, vxb.z, vxb.w};
+				const float vys[8] = {vya.x, vya.y, vya.z, vya.w, vyb.x, vyb.y, vyb.z, vyb.w};
+				const float dxs[8] = {dxa.x, dxa.y, dxa.z, dxa.w, dxb.x, dxb.y, dxb.z, dxb.w};
+				const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
+				const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
+				const uint32_t base = gq * GRP;
+#pragma unroll
+				for (uint32_t j = 0; j < GRP; j++) {
+					const float F = sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]);
+					const uint32_t key = (__float_as_uint(F) & ~IDX_MASK) | base | j;
+					k4 = umed3(k3, k4, key); // sorted quadruple: clamp(key, k_{j-1}, k_j)
+					k3 = umed3(k2, k3, key);
+					k2 = umed3(k1, k2, key);
+					k1 = min(k1, key);
+				}
+			}
+		}
+
+		if (!(ABL & 4)) {
+			if (!sane) {
+				for (uint32_t j = 0; j < cnt; j++)
+					exact_lds(j);
+			} else if (k1 != 0xFFFFFFFFu) {
+				// ---- exact evaluation of the candidates that cannot be excluded (as in sdf_tiles_filtered) ----
+				const float M = Mc;
+				const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
+				const float f1 = __uint_as_float(k1 & ~IDX_MASK) * KEY_SLACK;
+				float U = f1 + filter_err(f1, M) + e64;
+				if (!(U >= 0.0f))
+					U = __builtin_inff();
+				auto excluded = [&](uint32_t key) {
+					const float fk = __uint_as_float(key & ~IDX_MASK);
+					return fk - filter_err(fk * KEY_SLACK, M) - e64 > U; // false for NaN / inf U
+				};
+				auto real = [&](uint32_t key) { return key != 0xFFFFFFFFu && (key & IDX_MASK) < cnt; };
+				if (real(k1))
+					exact_lds(k1 & IDX_MASK);
+				if (real(k2) && !excluded(k2))
+					exact_lds(k2 & IDX_MASK);
+				if (real(k3) && !excluded(k3))
+					exact_lds(k3 & IDX_MASK);
+				if (k4 != 0xFFFFFFFFu && !excluded(k4)) {
+					if (real(k4))
+						exact_lds(k4 & IDX_MASK);
+					// four near-ties: rescan the candidate groups against a verified key threshold
+					float Tk = U + e64;
+					for (int it = 0; it < 3; it++)
+						Tk = U + e64 + filter_err(Tk * KEY_SLACK, M);
+					Tk = Tk * 1.001f + 1e-30f;
+					if (!(Tk - filter_err(Tk * KEY_SLACK, M) - e64 > U))
+						Tk = __builtin_inff();
+					uint32_t m = cand;
+					while (m) {
+						const uint32_t gq = (uint32_t)__builtin_ctz(m);
+						m &= m - 1;
+						for (uint32_t j = gq * GRP; j < min(gq * GRP + GRP, cnt); j++) {
+							const float F = sc_filter(rpx, rpy, s_vx[j], s_vy[j], s_dx[j], s_dy[j], s_inv[j]);
+							const float fk = __uint_as_float(__float_as_uint(F) & ~IDX_MASK);
+							if (!(fk > Tk))
+								exact_lds(j);
+						}
+					}
+				}
+			}
+			// the exact minimum so far bounds the later chunks too
+			const float bf = (float)best * (1.0f + 1.0f / 1048576.0f);
+			ub2 = bf < ub2 ? bf : ub2;
+		}
+	}
+
+	if (active) {
+		// winding number = prefix sum of the row's histogram up to this column
+		int wn = 0;
+		const int *drow = s_delta + (row - r_first) * stride;
+		for (uint32_t k = 0; k <= x; k++)
+			wn += drow[k];
+		out[g.out_off + o] = quantise(best, wn != 0);
+	}
+}
+
 } // namespace vgsdf
 
 // ---------------------------------------------------------------------------------------
@@ -882,12 +1185,27 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 #define VG_LAUNCH_PK(A, C, P)                                                                            \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C, P>), grid, dim3(vgsdf::TPB / P), 0, stream, glyphs, tiles,  \
 	                   n_tiles, sx, sy, ex, ey, out)
+#define VG_LAUNCH_HIER(A)                                                                                 \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_hier<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
+	                   sx, sy, ex, ey, out)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
 	if (variant == 1)
 		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
 		                   tiles, n_tiles, sx, sy, ex, ey, out);
+	else if (variant == 30) // bounded groups
+		VG_LAUNCH_HIER(0);
+	else if (variant == 31) // timing-only: no phase 2
+		VG_LAUNCH_HIER(2);
+	else if (variant == 32) // timing-only: no phase 2, no exact
+		VG_LAUNCH_HIER(6);
+	else if (variant == 33) // timing-only: staging only (no winding, phases, exact)
+		VG_LAUNCH_HIER(39);
+	else if (variant == 34) // timing-only: no winding
+		VG_LAUNCH_HIER(1);
+	else if (variant == 35) // timing-only: no exact evaluation
+		VG_LAUNCH_HIER(4);
 	else if (variant >= 100) { // timing-only ablations 100 + mask
 		switch (variant - 100) {
 		case 1: VG_LAUNCH_FILTERED(1, true); break;

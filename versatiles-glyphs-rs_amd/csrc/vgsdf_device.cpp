@@ -537,10 +537,10 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
-	const bool all_plain = v == 2 || v == 12 || v == 22 || (v >= 54 && v <= 57), all_cull = v == 3 || v == 13 || v == 23 || v >= 100;
+	const bool all_plain = v == 2 || v == 12 || v == 22 || (v >= 30 && v <= 39) || (v >= 54 && v <= 57), all_cull = v == 3 || v == 13 || v == 23 || v >= 100;
 	const uint32_t n_plain = v == 1 ? 0 : (all_plain ? n_main : (all_cull ? 0 : b->n_plain));
 	const int list_order = b->tile_order == 1;
-	const int k_plain = v == 0 ? 22 : ((v == 12 || v == 22) ? v : ((v >= 54 && v <= 57) ? v : 2));
+	const int k_plain = v == 0 ? 22 : ((v == 12 || v == 22 || (v >= 30 && v <= 39)) ? v : ((v >= 54 && v <= 57) ? v : 2));
 	const int k_cull = v >= 100 ? v : ((v == 13 || v == 0) ? 10 : (v == 23 ? 23 : 0));
 	int e = vgsdf_launch_tiles(k_plain, list_order, b->d_glyphs, b->d_tiles, n_plain, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
 	                           b->d_out, ctx->stream);
