@@ -24,7 +24,7 @@ def run_both(oracle, vg, ctx, glyphs, mode=None):
     """glyphs: [(segs, x0, y0, w, h)] -> asserts both variants equal the oracle"""
     batch = vg.make_batch(glyphs)
     want, _ = oracle.sdf_render_batch(batch, oracle.BRUTE if mode is None else mode, 4)
-    for variant in (0, 1, 2, 3, 12, 13, 22, 23, 30):  # routed (default), brute, packed 2px/lane never/always culled, scalar ditto, packed 1px/lane ditto
+    for variant in (0, 1, 2, 3, 12, 13, 22, 23, 30, 45):  # routed (default), brute, packed 2px/lane never/always culled, scalar ditto, packed 1px/lane ditto
         ctx.set_variant(variant)
         got = ctx.render_batch(batch)
         diff = np.flatnonzero(got != want)
@@ -94,6 +94,47 @@ def test_many_ties_queue_overflow(oracle, vg, ctx):
     run_both(oracle, vg, ctx, [(segs, 0, 0, 12, 12)])
 
 
+def test_distances_on_rounding_boundaries(oracle, vg, ctx):
+    """axis-aligned edges at multiples of 1/64 px: 32 d is a multiple of 1/2 for most pixels, i.e.
+    exactly ON the byte rounding boundary for half of them (the bounded-group kernel may only skip
+    the f64 evaluation when the whole error interval is strictly inside one bin)"""
+    glyphs = []
+    for k in range(0, 64, 3):
+        o = k / 64.0
+        box = ring([(2 + o, 2 + o), (17 + o, 2 + o), (17 + o, 12 + o), (2 + o, 12 + o)])
+        hole = ring([(5 + o, 5.5), (5 + o, 9.5), (14.5, 9.5 + o), (14.5, 5.5)])
+        glyphs.append((np.concatenate([box, hole]), -1, -1, 22, 17))
+    run_both(oracle, vg, ctx, glyphs)
+
+
+def test_finely_flattened_outlines(oracle, vg, ctx):
+    """what real fonts look like after flattening at 0.1 font units: hundreds of sub-pixel segments
+    per ring, several 256-segment chunks, groups straddling ring boundaries and sharp corners"""
+    rng = np.random.default_rng(11)
+    glyphs = []
+    for n_sub in (7, 37, 150):
+        for _ in range(6):
+            segs = []
+            for k in range(3):
+                c = rng.uniform(8, 16, 2)
+                a = np.sort(rng.uniform(0, 2 * np.pi, 5))
+                r = rng.uniform(2, 7, 5)
+                corners = np.stack([c[0] + r * np.cos(a), c[1] + r * np.sin(a)], 1)
+                pts = []
+                for i in range(5):
+                    p, q = corners[i], corners[(i + 1) % 5]
+                    t = np.linspace(0, 1, n_sub, endpoint=False)[:, None]
+                    bulge = 0.6 * np.sin(np.pi * t) * np.array([[q[1] - p[1], p[0] - q[0]]]) / 8
+                    pts.append(p + t * (q - p) + bulge)
+                pts = np.concatenate(pts)
+                segs.append(ring(pts if k % 2 == 0 else pts[::-1]))
+            segs = np.concatenate(segs)
+            lo = np.floor(segs[:, [0, 1]].min(0)).astype(int) - 3
+            hi = np.ceil(segs[:, [0, 1]].max(0)).astype(int) + 3
+            glyphs.append((segs, int(lo[0]), int(lo[1]), int(hi[0] - lo[0]), int(hi[1] - lo[1])))
+    run_both(oracle, vg, ctx, glyphs)
+
+
 def test_wide_and_thin_rects(oracle, vg, ctx):
     rng = np.random.default_rng(3)
     wide = ring(np.stack([np.linspace(5, 1500, 60), 6 + 3 * np.sin(np.linspace(0, 20, 60))], 1).tolist()
@@ -127,7 +168,7 @@ def test_synthetic_first_outlines(oracle, vg, ctx):
     from versatiles_glyphs_rs_amd import synthetic as S
     batch = S.make_batch(0, 48)
     want, _ = oracle.sdf_render_batch(batch, oracle.PRECISE, 4)
-    for variant in (0, 1, 2, 3, 12, 13, 22, 23, 30):
+    for variant in (0, 1, 2, 3, 12, 13, 22, 23, 30, 45):
         ctx.set_variant(variant)
         assert np.array_equal(ctx.render_batch(batch), want)
     ctx.set_variant(0)

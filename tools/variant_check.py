@@ -25,7 +25,15 @@ for v in variants:
     db.launch()
     got = db.download()
     msg = ""
-    if v < 31:
+    if v == 44:
+        a = np.asarray(got)
+        w = np.array([(a[i:i+64] == 2).any() for i in range(0, len(a), 64)])
+        msg = f"rescan pixels: {(a == 2).mean():.4%}; 64-byte runs with one: {w.mean():.2%}"
+    elif v == 43:
+        a = np.asarray(got)
+        w = [a[i:i+64].min() for i in range(0, len(a), 64)]
+        msg = f"exact-path pixels: {(a == 0).mean():.4%}; 64-byte runs with one: {np.mean(np.array(w) == 0):.2%}"
+    elif v < 31 or v == 45:
         diff = np.flatnonzero(np.asarray(got) != np.asarray(want))
         msg = f"parity: {diff.size} bytes differ of {len(got)}"
     db.time(3)

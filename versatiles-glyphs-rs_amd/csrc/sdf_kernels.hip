@@ -881,7 +881,7 @@ __global__ __launch_bounds__(TPB / PPL) void sdf_tiles_pk(const GlyphDesc *__res
 // pad of 0.01 + 1e-5 M px (anchor and record end points are within 8 u M < 2e-3 px of the true
 // ones for M < 4096; D_g^2 has relative error < 2^-21).  For M >= 4096 every group is a candidate.
 // ---------------------------------------------------------------------------------------
-template <int ABL>
+template <int ABL, bool LAZY>
 __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restrict__ glyphs,
                                                       const uint2 *__restrict__ tiles, uint32_t n_tiles,
                                                       const double *__restrict__ seg_sx,
@@ -926,6 +926,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
 	double best = __builtin_huge_val(); // rtree_segments.rs:57
 	float ub2 = __builtin_inff();       // squared distance to the nearest anchor / exact candidate so far
+	float qmin = 1.0e9f;                // LAZY: smallest decided distance bin floor(32 d + 0.5) over the chunks
 
 	auto exact_lds = [&](uint32_t i) {
 		const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
@@ -1055,19 +1056,24 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 			ub2 = __uint_as_float(dmin);
 			float U = (__builtin_sqrtf(ub2) * INFL + pad) * INFL;
 			U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
-			cand = 0;
+			// One bit per group, 3 VALU ops each: tt = U + r_g, diff = tt^2 - D_g^2 (sign bit set <=> not
+			// a candidate; -inf for the groups past n_groups), shifted in with v_alignbit.  The bits
+			// arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
+			uint32_t rej = 0xFFFFFFFFu;
 #pragma unroll
 			for (uint32_t b = 0; b < NGRP / 4; b++) {
-				if (b * 4 < n_groups) {
-					const float4 r = gr4[b];
-					const float rs[4] = {r.x, r.y, r.z, r.w};
+				float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (b * 4 < n_groups)
+					r = gr4[b];
+				const float rs[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-					for (int j = 0; j < 4; j++) {
-						const float tt = U + rs[j];
-						cand |= (D2[b * 4 + j] <= tt * tt) ? (1u << (b * 4 + j)) : 0u;
-					}
+				for (int j = 0; j < 4; j++) {
+					const float tt = U + rs[j];
+					const float diff = __builtin_fmaf(tt, tt, -D2[b * 4 + j]);
+					rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(diff), 31); // (rej << 1) | sign(diff)
 				}
 			}
+			cand = __builtin_bitreverse32(~rej);
 		}
 
 		// ---- phase 2: f32 filter over the lane's candidate groups, sorted top-4 of (F | index) ----
@@ -1118,6 +1124,31 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 					return fk - filter_err(fk * KEY_SLACK, M) - e64 > U; // false for NaN / inf U
 				};
 				auto real = [&](uint32_t key) { return key != 0xFFFFFFFFu && (key & IDX_MASK) < cnt; };
+				bool decided = false;
+				if (LAZY && U < 1.0e30f) {
+					// The chunk's minimum C lies in [LB, U] (every candidate's key is >= k1, L is increasing
+					// for f >= c^2, c = 1.001 * 64 u M; segments of non-candidate groups are beyond the true
+					// minimum or beyond SAT, 6.16^2 = 38).  Both bytes are functions of the bin
+					// q = floor(32 sqrt(C) + 1/2) (renderer_precise.rs:71-79: 191 - q outside, 191 + q inside);
+					// if the whole interval falls into one bin no f64 work is needed for this chunk.  The
+					// reference's own roundings move 32 sqrt(C) by < 1e-12, the f32 evaluation by < 1e-4.
+					const float fk = __uint_as_float(k1 & ~IDX_MASK);
+					const float cc = 3.83e-6f * M;
+					float LB = fk > cc * cc ? fk - filter_err(fk * KEY_SLACK, M) - e64 : 0.0f;
+					LB = LB > 0.0f ? LB : 0.0f;
+					LB = LB < 38.0f ? LB : 38.0f;
+					const float Uc = U < 38.0f ? U : 38.0f;
+					const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 1.0e-3f));
+					const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 1.0e-3f));
+					if (q_lo == q_hi) {
+						qmin = q_lo < qmin ? q_lo : qmin;
+						decided = true;
+					}
+				}
+				if (decided) {
+					const float uf = U * (1.0f + 1.0f / 1048576.0f);
+					ub2 = uf < ub2 ? uf : ub2;
+				} else {
 				if (real(k1))
 					exact_lds(k1 & IDX_MASK);
 				if (real(k2) && !excluded(k2))
@@ -1146,6 +1177,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 						}
 					}
 				}
+				} // !decided
 			}
 			// the exact minimum so far bounds the later chunks too
 			const float bf = (float)best * (1.0f + 1.0f / 1048576.0f);
@@ -1159,7 +1191,14 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 		const int *drow = s_delta + (row - r_first) * stride;
 		for (uint32_t k = 0; k <= x; k++)
 			wn += drow[k];
-		out[g.out_off + o] = quantise(best, wn != 0);
+		uint8_t byte = quantise(best, wn != 0); // +inf (nothing evaluated exactly) -> 0 outside, 255 inside
+		if (LAZY && qmin < 1.0e8f) {
+			// the nearest segment gives the largest byte outside, the smallest inside
+			const int q = (int)qmin;
+			const int bq = wn != 0 ? min(191 + q, 255) : max(191 - q, 0);
+			byte = wn != 0 ? (uint8_t)min((int)byte, bq) : (uint8_t)max((int)byte, bq);
+		}
+		out[g.out_off + o] = byte;
 	}
 }
 
@@ -1185,8 +1224,8 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 #define VG_LAUNCH_PK(A, C, P)                                                                            \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C, P>), grid, dim3(vgsdf::TPB / P), 0, stream, glyphs, tiles,  \
 	                   n_tiles, sx, sy, ex, ey, out)
-#define VG_LAUNCH_HIER(A)                                                                                 \
-	hipLaunchKernelGGL((vgsdf::sdf_tiles_hier<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
+#define VG_LAUNCH_HIER(A, L)                                                                               \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_hier<A, L>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
 	                   sx, sy, ex, ey, out)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
@@ -1195,17 +1234,19 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
 		                   tiles, n_tiles, sx, sy, ex, ey, out);
 	else if (variant == 30) // bounded groups
-		VG_LAUNCH_HIER(0);
+		VG_LAUNCH_HIER(0, false);
+	else if (variant == 45) // bounded groups, exact evaluation only where the byte is undecided
+		VG_LAUNCH_HIER(0, true);
 	else if (variant == 31) // timing-only: no phase 2
-		VG_LAUNCH_HIER(2);
+		VG_LAUNCH_HIER(2, false);
 	else if (variant == 32) // timing-only: no phase 2, no exact
-		VG_LAUNCH_HIER(6);
+		VG_LAUNCH_HIER(6, false);
 	else if (variant == 33) // timing-only: staging only (no winding, phases, exact)
-		VG_LAUNCH_HIER(39);
+		VG_LAUNCH_HIER(39, false);
 	else if (variant == 34) // timing-only: no winding
-		VG_LAUNCH_HIER(1);
+		VG_LAUNCH_HIER(1, false);
 	else if (variant == 35) // timing-only: no exact evaluation
-		VG_LAUNCH_HIER(4);
+		VG_LAUNCH_HIER(4, false);
 	else if (variant >= 100) { // timing-only ablations 100 + mask
 		switch (variant - 100) {
 		case 1: VG_LAUNCH_FILTERED(1, true); break;

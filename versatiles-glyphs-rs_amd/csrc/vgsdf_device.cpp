@@ -244,9 +244,8 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 	const uint32_t n = in->n_glyphs;
 	// Routing.  A glyph goes to the brute-force kernel when its winding histogram (rows touched
 	// by 256 consecutive pixels, times w+1 columns) would not fit in LDS, or its segment index
-	// needs more than 24 bits.  Culling (per-wave candidate lists) only pays when a wave's strip
-	// of 64 pixels plus the 6.2 px saturation margin covers well under half of the bitmap: large
-	// glyphs.  Small glyphs (every real font at 24 px/EM) take the straight broadcast loop.
+	// needs more than 24 bits; everything else (class 0; every real font at 24 px/EM) takes the
+	// main kernel.
 	const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
 	auto klass = [&](uint32_t g) -> int {
 		const uint64_t w = in->w[g], h = in->h[g];
@@ -255,10 +254,7 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 		const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
 		if (rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24))
 			return 2;
-		const float strip_rows = (float)((63u + w) / w + 1u);
-		const float keep_y = std::min(1.0f, (strip_rows + 12.4f) / (float)h);
-		const float keep_x = w <= 64u ? 1.0f : std::min(1.0f, 76.4f / (float)w);
-		return keep_x * keep_y < 0.40f ? 1 : 0;
+		return 0;
 	};
 	const char *ord = std::getenv("VGSDF_TILE_ORDER");
 	b->tile_order = ord ? std::atoi(ord) : 1;
@@ -529,24 +525,20 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_E_ARG;
 	}
 	(void)hipSetDevice(ctx->device);
-	// variant 0: routed — small glyphs: packed grouped filter (1 px/lane); large glyphs: scalar
-	// filter with per-wave culling; misfits: brute force.  (Fastest measured combination.)
-	// 1: everything brute; 22 / 23: packed 1 px/lane never / always culled; 2 / 3: packed
-	// 2 px/lane never / always culled; 12 / 13: scalar top-4 filter never / always culled;
-	// 54-57: timing-only packed ablations; >= 100: timing-only ablations of the scalar instance
+	// variant 0 (default): bounded-group kernel for every tile the winding histogram fits; misfits:
+	// brute force.  1: everything brute.  A/B instances of the earlier generations: 22 / 23 packed
+	// grouped filter (1 px/lane) without / with per-wave culling; 2 / 3: the same with 2 px/lane;
+	// 12 / 13: scalar top-4 filter without / with culling; 30: bounded groups with the exact
+	// evaluation in every chunk; 45: same as 0; 31-39, 54-57, >= 100:
+	// timing-only ablations (wrong pixels)
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
-	const bool all_plain = v == 2 || v == 12 || v == 22 || (v >= 30 && v <= 39) || (v >= 54 && v <= 57), all_cull = v == 3 || v == 13 || v == 23 || v >= 100;
-	const uint32_t n_plain = v == 1 ? 0 : (all_plain ? n_main : (all_cull ? 0 : b->n_plain));
+	// kernel id understood by vgsdf_launch_tiles
+	const int k_main = v == 0 ? 45 : (v == 13 ? 10 : (v == 3 ? 0 : v));
 	const int list_order = b->tile_order == 1;
-	const int k_plain = v == 0 ? 22 : ((v == 12 || v == 22 || (v >= 30 && v <= 39)) ? v : ((v >= 54 && v <= 57) ? v : 2));
-	const int k_cull = v >= 100 ? v : ((v == 13 || v == 0) ? 10 : (v == 23 ? 23 : 0));
-	int e = vgsdf_launch_tiles(k_plain, list_order, b->d_glyphs, b->d_tiles, n_plain, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
+	int e = vgsdf_launch_tiles(k_main, list_order, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
 	                           b->d_out, ctx->stream);
-	if (e == 0)
-		e = vgsdf_launch_tiles(k_cull, list_order, b->d_glyphs, b->d_tiles + n_plain, n_main - n_plain, b->d_sx,
-		                       b->d_sy, b->d_ex, b->d_ey, b->d_out, ctx->stream);
 	if (e == 0)
 		e = vgsdf_launch_tiles(1, list_order, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
 		                       b->d_ey, b->d_out, ctx->stream);
