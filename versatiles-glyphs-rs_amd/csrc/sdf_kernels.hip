@@ -1095,14 +1095,28 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 				const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
 				const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
 				const uint32_t base = gq * GRP;
+				if (LAZY) {
+					// only the smallest filter value is tracked (F >= +0: unsigned order of the bits is float
+					// order): it decides the byte for ~99 % of the pixels; the rest rescans its candidates
+					uint32_t fb[GRP];
 #pragma unroll
-				for (uint32_t j = 0; j < GRP; j++) {
-					const float F = sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]);
-					const uint32_t key = (__float_as_uint(F) & ~IDX_MASK) | base | j;
-					k4 = umed3(k3, k4, key); // sorted quadruple: clamp(key, k_{j-1}, k_j)
-					k3 = umed3(k2, k3, key);
-					k2 = umed3(k1, k2, key);
-					k1 = min(k1, key);
+					for (uint32_t j = 0; j < GRP; j++)
+						fb[j] = __float_as_uint(sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]));
+					uint32_t mn;
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(k1), "v"(fb[0]), "v"(fb[1]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[2]), "v"(fb[3]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[4]), "v"(fb[5]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(k1) : "v"(mn), "v"(fb[6]), "v"(fb[7]));
+				} else {
+#pragma unroll
+					for (uint32_t j = 0; j < GRP; j++) {
+						const float F = sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]);
+						const uint32_t key = (__float_as_uint(F) & ~IDX_MASK) | base | j;
+						k4 = umed3(k3, k4, key); // sorted quadruple: clamp(key, k_{j-1}, k_j)
+						k3 = umed3(k2, k3, key);
+						k2 = umed3(k1, k2, key);
+						k1 = min(k1, key);
+					}
 				}
 			}
 		}
@@ -1112,72 +1126,85 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 				for (uint32_t j = 0; j < cnt; j++)
 					exact_lds(j);
 			} else if (k1 != 0xFFFFFFFFu) {
-				// ---- exact evaluation of the candidates that cannot be excluded (as in sdf_tiles_filtered) ----
 				const float M = Mc;
 				const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
-				const float f1 = __uint_as_float(k1 & ~IDX_MASK) * KEY_SLACK;
+				// keys carry the index in their low bits (truncated value fk <= F <= fk SLACK); LAZY keeps F itself
+				const uint32_t val_mask = LAZY ? 0xFFFFFFFFu : ~IDX_MASK;
+				const float SLACK = LAZY ? 1.0f : KEY_SLACK;
+				const float f1 = __uint_as_float(k1 & val_mask) * SLACK;
 				float U = f1 + filter_err(f1, M) + e64;
 				if (!(U >= 0.0f))
 					U = __builtin_inff();
 				auto excluded = [&](uint32_t key) {
-					const float fk = __uint_as_float(key & ~IDX_MASK);
-					return fk - filter_err(fk * KEY_SLACK, M) - e64 > U; // false for NaN / inf U
+					const float fk = __uint_as_float(key & val_mask);
+					return fk - filter_err(fk * SLACK, M) - e64 > U; // false for NaN / inf U
 				};
 				auto real = [&](uint32_t key) { return key != 0xFFFFFFFFu && (key & IDX_MASK) < cnt; };
-				bool decided = false;
-				if (LAZY && U < 1.0e30f) {
-					// The chunk's minimum C lies in [LB, U] (every candidate's key is >= k1, L is increasing
-					// for f >= c^2, c = 1.001 * 64 u M; segments of non-candidate groups are beyond the true
-					// minimum or beyond SAT, 6.16^2 = 38).  Both bytes are functions of the bin
-					// q = floor(32 sqrt(C) + 1/2) (renderer_precise.rs:71-79: 191 - q outside, 191 + q inside);
-					// if the whole interval falls into one bin no f64 work is needed for this chunk.  The
-					// reference's own roundings move 32 sqrt(C) by < 1e-12, the f32 evaluation by < 1e-4.
-					const float fk = __uint_as_float(k1 & ~IDX_MASK);
-					const float cc = 3.83e-6f * M;
-					float LB = fk > cc * cc ? fk - filter_err(fk * KEY_SLACK, M) - e64 : 0.0f;
-					LB = LB > 0.0f ? LB : 0.0f;
-					LB = LB < 38.0f ? LB : 38.0f;
-					const float Uc = U < 38.0f ? U : 38.0f;
-					const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 1.0e-3f));
-					const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 1.0e-3f));
-					if (q_lo == q_hi) {
-						qmin = q_lo < qmin ? q_lo : qmin;
-						decided = true;
-					}
-				}
-				if (decided) {
-					const float uf = U * (1.0f + 1.0f / 1048576.0f);
-					ub2 = uf < ub2 ? uf : ub2;
-				} else {
-				if (real(k1))
-					exact_lds(k1 & IDX_MASK);
-				if (real(k2) && !excluded(k2))
-					exact_lds(k2 & IDX_MASK);
-				if (real(k3) && !excluded(k3))
-					exact_lds(k3 & IDX_MASK);
-				if (k4 != 0xFFFFFFFFu && !excluded(k4)) {
-					if (real(k4))
-						exact_lds(k4 & IDX_MASK);
-					// four near-ties: rescan the candidate groups against a verified key threshold
+				// rescan of the lane's candidate groups against a key threshold Tk with L(Tk) > U (L increasing
+				// above it): fixed-point iteration for the crossing, pushed up, then VERIFIED; if the check
+				// fails nothing is excluded (Tk = inf)
+				auto rescan = [&]() {
 					float Tk = U + e64;
 					for (int it = 0; it < 3; it++)
-						Tk = U + e64 + filter_err(Tk * KEY_SLACK, M);
+						Tk = U + e64 + filter_err(Tk * SLACK, M);
 					Tk = Tk * 1.001f + 1e-30f;
-					if (!(Tk - filter_err(Tk * KEY_SLACK, M) - e64 > U))
+					if (!(Tk - filter_err(Tk * SLACK, M) - e64 > U))
 						Tk = __builtin_inff();
 					uint32_t m = cand;
 					while (m) {
 						const uint32_t gq = (uint32_t)__builtin_ctz(m);
 						m &= m - 1;
-						for (uint32_t j = gq * GRP; j < min(gq * GRP + GRP, cnt); j++) {
+						const uint32_t je = gq * GRP + GRP < cnt ? gq * GRP + GRP : cnt;
+						for (uint32_t j = gq * GRP; j < je; j++) {
 							const float F = sc_filter(rpx, rpy, s_vx[j], s_vy[j], s_dx[j], s_dy[j], s_inv[j]);
-							const float fk = __uint_as_float(__float_as_uint(F) & ~IDX_MASK);
+							const float fk = __uint_as_float(__float_as_uint(F) & val_mask);
 							if (!(fk > Tk))
 								exact_lds(j);
 						}
 					}
+				};
+				if (LAZY) {
+					// The chunk's minimum C lies in [LB, U] (every candidate's F is >= the smallest one, L is
+					// increasing for f >= c^2, c = 1.001 * 64 u M; segments of non-candidate groups are beyond
+					// the true minimum or beyond SAT, 6.16^2 = 38).  Both bytes are functions of the bin
+					// q = floor(32 sqrt(C) + 1/2) (renderer_precise.rs:71-79: 191 - q outside, 191 + q inside);
+					// if the whole interval falls into one bin no f64 work is needed for this chunk.  The
+					// reference's own roundings move 32 sqrt(C) by < 1e-12, the f32 evaluation by < 1e-4.
+					bool decided = false;
+					if (U < 1.0e30f) {
+						const float fk = __uint_as_float(k1);
+						const float cc = 3.83e-6f * M;
+						float LB = fk > cc * cc ? fk - filter_err(fk, M) - e64 : 0.0f;
+						LB = LB > 0.0f ? LB : 0.0f;
+						LB = LB < 38.0f ? LB : 38.0f;
+						const float Uc = U < 38.0f ? U : 38.0f;
+						const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 1.0e-3f));
+						const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 1.0e-3f));
+						if (q_lo == q_hi) {
+							qmin = q_lo < qmin ? q_lo : qmin;
+							decided = true;
+						}
+					}
+					if (decided) {
+						const float uf = U * (1.0f + 1.0f / 1048576.0f);
+						ub2 = uf < ub2 ? uf : ub2;
+					} else {
+						rescan(); // every candidate that cannot be excluded is evaluated exactly
+					}
+				} else {
+					// ---- exact evaluation of the candidates that cannot be excluded (as in sdf_tiles_filtered) ----
+					if (real(k1))
+						exact_lds(k1 & IDX_MASK);
+					if (real(k2) && !excluded(k2))
+						exact_lds(k2 & IDX_MASK);
+					if (real(k3) && !excluded(k3))
+						exact_lds(k3 & IDX_MASK);
+					if (k4 != 0xFFFFFFFFu && !excluded(k4)) {
+						if (real(k4))
+							exact_lds(k4 & IDX_MASK);
+						rescan(); // four near-ties: more may hide behind them
+					}
 				}
-				} // !decided
 			}
 			// the exact minimum so far bounds the later chunks too
 			const float bf = (float)best * (1.0f + 1.0f / 1048576.0f);
@@ -1199,6 +1226,352 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 			byte = wn != 0 ? (uint8_t)min((int)byte, bq) : (uint8_t)max((int)byte, bq);
 		}
 		out[g.out_off + o] = byte;
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Variant 0 (default): bounded groups over SPANS.  Same bounds, filter, bin decision and exact
+// fallback as sdf_tiles_hier<.., LAZY>; what changes is the unit of work of a workgroup: up to
+// SPAN = 4 consecutive 256-pixel tiles of ONE glyph.  A chunk of segments is staged (f64 loads,
+// f32 records, row crossings, group bounds) ONCE and then swept by the span's tiles one after the
+// other, so a glyph of <= 1024 pixels (99.7 % of Noto Sans) reads its segments from HBM/L2 once
+// and pays the staging arithmetic once, instead of once per tile.  Per-pixel state between chunks
+// (upper bound of the squared distance, the two candidate bytes) lives in LDS.
+//   tiles[i] = (glyph, first pixel | T): T in 1..4 tiles, chosen by the host so that the rows the
+//   span touches fit the winding histogram.
+// Because quantisation is monotone in the distance, the minimum over chunks can be taken on the
+// BYTES: outside the nearest segment gives the largest byte, inside the smallest; both are kept
+// until the winding number (complete only after the last chunk) picks one.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t SPAN_TILES = 4;
+
+template <int ABL>
+__global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__restrict__ glyphs,
+                                                      const uint2 *__restrict__ tiles, uint32_t n_tiles,
+                                                      const double *__restrict__ seg_sx,
+                                                      const double *__restrict__ seg_sy,
+                                                      const double *__restrict__ seg_ex,
+                                                      const double *__restrict__ seg_ey,
+                                                      uint8_t *__restrict__ out)
+{
+	constexpr uint32_t GRP = 8, NGRP = FCHUNK / GRP; // 32 groups per chunk: one mask bit each
+	static_assert(NGRP == 32 && TPB == FCHUNK, "one candidate bit per group, one staging thread per record");
+	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
+	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
+	__shared__ int s_delta[DELTA_CAP];
+	__shared__ uint32_t s_mbits;
+	__shared__ __attribute__((aligned(16))) float s_gx[NGRP], s_gy[NGRP], s_gr[NGRP]; // anchor, radius
+	__shared__ float st_ub2[SPAN_TILES * TPB];    // per pixel: upper bound of the squared distance so far
+	__shared__ uint16_t st_byte[SPAN_TILES * TPB]; // per pixel: byte if inside (low), byte if outside (high)
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
+	const uint2 t = tiles[tile];
+	const GlyphDesc g = glyphs[t.x];
+	const uint32_t npix = g.w * g.h;
+	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
+	const uint32_t p0 = t.y & ~255u, T = min(max(t.y & 255u, 1u), SPAN_TILES);
+	const uint32_t p_end = min(p0 + T * (uint32_t)TPB, npix); // pixels [p0, p_end) of the glyph's bitmap
+
+	const uint32_t r_first = p0 / g.w, r_last = (p_end - 1) / g.w;
+	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
+	const uint32_t stride = g.w + 1;
+	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
+	for (uint32_t i = tid; i < n_delta; i += TPB)
+		s_delta[i] = 0;
+	for (uint32_t k = 0; k < T; k++) {
+		st_ub2[k * TPB + tid] = __builtin_inff();
+		st_byte[k * TPB + tid] = 0x00FFu; // neutral: 255 for the min (inside), 0 for the max (outside)
+	}
+
+	const float wh = (float)max(g.w, g.h);
+	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
+	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
+
+	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
+		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
+		__syncthreads(); // previous chunk fully consumed (and s_delta / state initialised on the first trip)
+		if (tid == 0)
+			s_mbits = __float_as_uint(wh);
+		__syncthreads();
+
+		// ---- stage (thread i <-> record i): exact endpoints, f32 record, coordinate bound, crossings ----
+		{
+			const uint32_t i = tid;
+			float mf = 0.0f;
+			if (i >= cnt) { // pad the chunk with records that can never win (F = 2e36)
+				s_vx[i] = 1.0e18f;
+				s_vy[i] = 1.0e18f;
+				s_dx[i] = 0.0f;
+				s_dy[i] = 0.0f;
+				s_inv[i] = 0.0f;
+			} else {
+				const uint32_t s = g.seg_off + c0 + i;
+				const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
+				e_vx[i] = vx;
+				e_vy[i] = vy;
+				e_wx[i] = wx;
+				e_wy[i] = wy;
+				const double dx = wx - vx, dy = wy - vy;
+				const double l2 = dx * dx + dy * dy;
+				const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
+				const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
+				s_vx[i] = (float)rvx;
+				s_vy[i] = (float)rvy;
+				s_dx[i] = (float)dx;
+				s_dy[i] = (float)dy;
+				s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
+				const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
+				mf = (float)m * 1.000001f;               // round up
+				mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
+				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
+				if (vy != wy) {
+					const bool up = vy < wy;
+					const double lo = up ? vy : wy, hi = up ? wy : vy;
+					const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
+					const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
+					for (int yy = ya; yy < yb; yy++) {
+						const double pyy = (double)yy + y0c;
+						const double tc = (pyy - vy) / dy;
+						const double xc = vx + tc * dx;               // :45-46 / :48-49
+						const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
+						if (k < (int)g.w)
+							atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
+					}
+				}
+			}
+			// coordinate bound: wave maximum first, one LDS atomic per wave (non-negative floats order like uints)
+			uint32_t mb = __float_as_uint(mf);
+			for (int sh = 32; sh > 0; sh >>= 1)
+				mb = max(mb, (uint32_t)__shfl_xor((int)mb, sh));
+			if ((tid & 63) == 0)
+				atomicMax(&s_mbits, mb);
+		}
+		__syncthreads();
+		const float Mc = __uint_as_float(s_mbits);
+		const bool sane = Mc < 1.0e6f;   // else: no usable f32 bound -> every segment is evaluated exactly
+		const bool bounded = Mc < 4096.0f; // group bounds have a useful margin
+		const float pad = 0.01f + 1.0e-5f * Mc;
+		constexpr float INFL = 1.0f + 1.0f / 512.0f;
+		const uint32_t n_groups = (cnt + GRP - 1) / GRP;
+
+		// ---- group bounds: anchor = start vertex of the middle member, radius over all end points ----
+		{
+			const uint32_t gb = tid & ~(GRP - 1);
+			const uint32_t ai = min(gb + GRP / 2, cnt - 1);
+			const float ax = s_vx[ai], ay = s_vy[ai];
+			float r2 = 0.0f;
+			if (tid < cnt) {
+				const float vx = s_vx[tid], vy = s_vy[tid];
+				const float wx = vx + s_dx[tid], wy = vy + s_dy[tid];
+				const float ex = vx - ax, ey = vy - ay, fx = wx - ax, fy = wy - ay;
+				const float dv = __builtin_fmaf(ey, ey, ex * ex), dw = __builtin_fmaf(fy, fy, fx * fx);
+				r2 = dv > dw ? dv : dw;
+			}
+			for (int sh = 1; sh < (int)GRP; sh <<= 1) {
+				const float other = __shfl_xor(r2, sh);
+				r2 = other > r2 ? other : r2;
+			}
+			if ((tid & (GRP - 1)) == 0) {
+				const bool empty = gb >= cnt;
+				s_gx[tid / GRP] = empty ? 1.0e18f : ax;
+				s_gy[tid / GRP] = empty ? 1.0e18f : ay;
+				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL;
+			}
+		}
+		__syncthreads();
+
+		const float4 *q_vx = reinterpret_cast<const float4 *>(s_vx), *q_vy = reinterpret_cast<const float4 *>(s_vy);
+		const float4 *q_dx = reinterpret_cast<const float4 *>(s_dx), *q_dy = reinterpret_cast<const float4 *>(s_dy);
+		const float4 *q_inv = reinterpret_cast<const float4 *>(s_inv);
+		const float M = Mc;
+		const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
+
+		// ---- sweep: every tile of the span against the staged chunk ----
+#pragma unroll 1
+		for (uint32_t k = 0; k < T; k++) {
+			// compiler barrier: keeps the (loop-invariant, wave-uniform) group-bound loads inside the loop
+			// instead of parking 96 VGPRs of them across it
+			asm volatile("" ::: "memory");
+			const uint32_t o = p0 + k * TPB + tid;
+			const uint32_t oc = o < npix ? o : npix - 1;
+			const uint32_t row = oc / g.w;
+			const uint32_t x = oc - row * g.w;
+			const uint32_t y = g.h - 1 - row;
+			const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
+			float ub2 = st_ub2[k * TPB + tid];
+
+			// ---- phase 1: candidate groups of this lane ----
+			uint32_t cand = n_groups >= 32 ? 0xFFFFFFFFu : ((1u << n_groups) - 1u);
+			if (bounded) {
+				float D2[NGRP];
+				uint32_t dmin = __float_as_uint(ub2);
+				const float4 *gx4 = reinterpret_cast<const float4 *>(s_gx), *gy4 = reinterpret_cast<const float4 *>(s_gy);
+				const float4 *gr4 = reinterpret_cast<const float4 *>(s_gr);
+	#pragma unroll
+				for (uint32_t b = 0; b < NGRP / 4; b++) {
+					if (b * 4 < n_groups) {
+						const float4 ax = gx4[b], ay = gy4[b];
+						const float axs[4] = {ax.x, ax.y, ax.z, ax.w}, ays[4] = {ay.x, ay.y, ay.z, ay.w};
+	#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							const float ddx = rpx - axs[j], ddy = rpy - ays[j];
+							const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
+							D2[b * 4 + j] = d2;
+							dmin = min(dmin, __float_as_uint(d2)); // d2 >= +0: unsigned order is float order
+						}
+					} else {
+	#pragma unroll
+						for (int j = 0; j < 4; j++)
+							D2[b * 4 + j] = __builtin_inff();
+					}
+				}
+				ub2 = __uint_as_float(dmin);
+				float U = (__builtin_sqrtf(ub2) * INFL + pad) * INFL;
+				U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
+				// One bit per group, 3 VALU ops each: tt = U + r_g, diff = tt^2 - D_g^2 (sign bit set <=> not
+				// a candidate; -inf for the groups past n_groups), shifted in with v_alignbit.  The bits
+				// arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
+				uint32_t rej = 0xFFFFFFFFu;
+	#pragma unroll
+				for (uint32_t b = 0; b < NGRP / 4; b++) {
+					float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					if (b * 4 < n_groups)
+						r = gr4[b];
+					const float rs[4] = {r.x, r.y, r.z, r.w};
+	#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const float tt = U + rs[j];
+						const float diff = __builtin_fmaf(tt, tt, -D2[b * 4 + j]);
+						rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(diff), 31); // (rej << 1) | sign(diff)
+					}
+				}
+				cand = __builtin_bitreverse32(~rej);
+			}
+
+
+			// ---- phase 2: smallest f32 filter value over the lane's candidate groups (F >= +0: unsigned
+			// order of the bits is float order) ----
+			uint32_t k1 = 0xFFFFFFFFu;
+			if (sane) {
+				uint32_t m = cand;
+				while (m) {
+					const uint32_t gq = (uint32_t)__builtin_ctz(m);
+					m &= m - 1;
+					const float4 vxa = q_vx[2 * gq], vya = q_vy[2 * gq], dxa = q_dx[2 * gq], dya = q_dy[2 * gq], iva = q_inv[2 * gq];
+					const float4 vxb = q_vx[2 * gq + 1], vyb = q_vy[2 * gq + 1], dxb = q_dx[2 * gq + 1], dyb = q_dy[2 * gq + 1],
+					             ivb = q_inv[2 * gq + 1];
+					const float vxs[8] = {vxa.x, vxa.y, vxa.z, vxa.w, vxb.x, vxb.y, vxb.z, vxb.w};
+					const float vys[8] = {vya.x, vya.y, vya.z, vya.w, vyb.x, vyb.y, vyb.z, vyb.w};
+					const float dxs[8] = {dxa.x, dxa.y, dxa.z, dxa.w, dxb.x, dxb.y, dxb.z, dxb.w};
+					const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
+					const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
+					uint32_t fb[GRP];
+#pragma unroll
+					for (uint32_t j = 0; j < GRP; j++)
+						fb[j] = __float_as_uint(sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]));
+					uint32_t mn;
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(k1), "v"(fb[0]), "v"(fb[1]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[2]), "v"(fb[3]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[4]), "v"(fb[5]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(k1) : "v"(mn), "v"(fb[6]), "v"(fb[7]));
+				}
+			}
+
+			// ---- decide.  The chunk's minimum C lies in [LB, U] (every candidate's F is >= the smallest
+			// one, L(f) = f - h(f) - e64 is increasing for f >= c^2, c = 1.001 * 64 u M; segments of
+			// non-candidate groups are beyond the true minimum or beyond SAT, 6.16^2 = 38).  Both bytes
+			// are functions of the bin q = floor(32 sqrt(C) + 1/2) (renderer_precise.rs:71-79: 191 - q
+			// outside, 191 + q inside); if the whole interval falls into one bin no f64 work is needed.
+			// The reference's own roundings move 32 sqrt(C) by < 1e-12, the f32 evaluation by < 1e-4. ----
+			bool have = false;
+			uint32_t b_in = 255u, b_out = 0u;
+			double best = __builtin_huge_val(); // rtree_segments.rs:57
+			const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
+			auto exact_lds = [&](uint32_t i) {
+				const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
+				const double dx = wx - vx, dy = wy - vy; // segment.rs:63
+				const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
+				best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
+			};
+			if (!sane) {
+				for (uint32_t j = 0; j < cnt; j++)
+					exact_lds(j);
+				have = true;
+			} else if (k1 != 0xFFFFFFFFu) {
+				const float f1 = __uint_as_float(k1);
+				float U = f1 + filter_err(f1, M) + e64;
+				if (!(U >= 0.0f))
+					U = __builtin_inff();
+				bool decided = false;
+				if (U < 1.0e30f) {
+					const float cc = 3.83e-6f * M;
+					float LB = f1 > cc * cc ? f1 - filter_err(f1, M) - e64 : 0.0f;
+					LB = LB > 0.0f ? LB : 0.0f;
+					LB = LB < 38.0f ? LB : 38.0f;
+					const float Uc = U < 38.0f ? U : 38.0f;
+					const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 1.0e-3f));
+					const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 1.0e-3f));
+					if (q_lo == q_hi) {
+						const int q = (int)q_lo;
+						b_in = (uint32_t)min(191 + q, 255);
+						b_out = (uint32_t)max(191 - q, 0);
+						decided = true;
+					}
+					const float uf = U * (1.0f + 1.0f / 1048576.0f);
+					ub2 = uf < ub2 ? uf : ub2; // bounds the later chunks' candidates too
+				}
+				if (!decided) {
+					// Rescan of the lane's candidate groups against a threshold Tk with L(Tk) > U (L increasing
+					// above it): fixed-point iteration for the crossing, pushed up, then VERIFIED; if the check
+					// fails nothing is excluded (Tk = inf).  Everything at or below Tk is evaluated exactly.
+					float Tk = U + e64;
+					for (int it = 0; it < 3; it++)
+						Tk = U + e64 + filter_err(Tk, M);
+					Tk = Tk * 1.001f + 1e-30f;
+					if (!(Tk - filter_err(Tk, M) - e64 > U))
+						Tk = __builtin_inff();
+					uint32_t m = cand;
+					while (m) {
+						const uint32_t gq = (uint32_t)__builtin_ctz(m);
+						m &= m - 1;
+						const uint32_t je = gq * GRP + GRP < cnt ? gq * GRP + GRP : cnt;
+						for (uint32_t j = gq * GRP; j < je; j++) {
+							const float F = sc_filter(rpx, rpy, s_vx[j], s_vy[j], s_dx[j], s_dy[j], s_inv[j]);
+							if (!(F > Tk))
+								exact_lds(j);
+						}
+					}
+					have = true;
+				}
+			}
+			if (have) {
+				b_in = quantise(best, true);
+				b_out = quantise(best, false);
+			}
+			// minimum over the chunks, taken on the bytes (monotone in the distance)
+			const uint32_t old = st_byte[k * TPB + tid];
+			b_in = min(b_in, old & 255u);
+			b_out = max(b_out, old >> 8);
+			st_byte[k * TPB + tid] = (uint16_t)(b_in | (b_out << 8));
+			st_ub2[k * TPB + tid] = ub2;
+		}
+	}
+
+	// ---- winding number = prefix sum of the row's histogram up to the pixel's column; pick the byte ----
+	__syncthreads(); // n_seg == 0: the initial state / zeroed histogram must be visible
+	for (uint32_t k = 0; k < T; k++) {
+		const uint32_t o = p0 + k * TPB + tid;
+		if (o < npix) {
+			const uint32_t row = o / g.w;
+			const uint32_t x = o - row * g.w;
+			int wn = 0;
+			const int *drow = s_delta + (row - r_first) * stride;
+			for (uint32_t c = 0; c <= x; c++)
+				wn += drow[c];
+			const uint32_t sb = st_byte[k * TPB + tid];
+			out[g.out_off + o] = (uint8_t)(wn != 0 ? (sb & 255u) : (sb >> 8));
+		}
 	}
 }
 
@@ -1227,6 +1600,9 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 #define VG_LAUNCH_HIER(A, L)                                                                               \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_hier<A, L>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
 	                   sx, sy, ex, ey, out)
+#define VG_LAUNCH_SPAN(A)                                                                                 \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
+	                   sx, sy, ex, ey, out)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
@@ -1235,6 +1611,8 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		                   tiles, n_tiles, sx, sy, ex, ey, out);
 	else if (variant == 30) // bounded groups
 		VG_LAUNCH_HIER(0, false);
+	else if (variant == 50) // bounded groups over spans of up to 4 tiles (tile list: first pixel | T)
+		VG_LAUNCH_SPAN(0);
 	else if (variant == 45) // bounded groups, exact evaluation only where the byte is undecided
 		VG_LAUNCH_HIER(0, true);
 	else if (variant == 31) // timing-only: no phase 2

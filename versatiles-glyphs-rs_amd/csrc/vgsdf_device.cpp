@@ -65,6 +65,7 @@ struct vgsdf_dbatch {
 	uint32_t n_main = 0; // tiles [0, n_main): filtered kernel (both flavours)
 	uint32_t n_plain = 0; // tiles [0, n_plain): filtered without culling (small glyphs)
 	int tile_order = 1;
+	bool span_list = false; // main-class entries are (glyph, first pixel | tile count): sdf_tiles_span only
 	bool borrowed = false; // arena + staging belong to the context (vgsdf_render_batch)
 };
 
@@ -239,7 +240,7 @@ int vgsdf_batch_free(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 
 // Fills the glyph descriptors and the tile list (routing + order) of a batch.  `ht` must hold
 // stats.n_tiles entries.  Shared by the segment entry points and the outline front-end.
-static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, uint2 *ht, vgsdf_dbatch *b)
+static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, uint2 *ht, vgsdf_dbatch *b, bool span)
 {
 	const uint32_t n = in->n_glyphs;
 	// Routing.  A glyph goes to the brute-force kernel when its winding histogram (rows touched
@@ -247,15 +248,37 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 	// needs more than 24 bits; everything else (class 0; every real font at 24 px/EM) takes the
 	// main kernel.
 	const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
+	// rows touched by T consecutive tiles, times w+1 columns, must fit the winding histogram
+	auto fits = [&](uint64_t w, uint64_t T) { return ((VGSDF_TILE_PIXELS * T - 2) / w + 2) * (w + 1) <= delta_cap; };
+	// span list (default kernel): a workgroup takes up to 4 consecutive tiles of one glyph, the
+	// largest count whose rows fit; the entry is (glyph, first pixel | count)
+	const char *sm = std::getenv("VGSDF_SPAN_MAX");
+	const uint32_t span_max = sm ? (uint32_t)std::min(4, std::max(1, std::atoi(sm))) : 4u;
+	const char *sb = std::getenv("VGSDF_SPAN_BUDGET");
+	const uint32_t span_budget = sb ? (uint32_t)std::max(1, std::atoi(sb)) : 16u; // measured: 12-24 equally good
+	auto span_tiles = [&](uint32_t g) -> uint32_t {
+		if (!span)
+			return 1;
+		const uint64_t w = in->w[g];
+		// a workgroup sweeps T tiles per staged chunk, one after the other: keep tiles x chunks bounded
+		// so that the glyphs with long segment lists stay spread over many workgroups (they set the
+		// makespan of a small batch) while the short ones are staged once
+		const uint32_t chunks = (in->seg_off[g + 1] - in->seg_off[g] + 255u) / 256u;
+		const uint32_t t_hi = std::min(span_max, std::max(1u, span_budget / std::max(chunks, 1u)));
+		for (uint32_t T = t_hi; T > 1; T--)
+			if (fits(w, T))
+				return T;
+		return 1;
+	};
 	auto klass = [&](uint32_t g) -> int {
 		const uint64_t w = in->w[g], h = in->h[g];
 		if (w == 0 || h == 0)
 			return 0;
-		const uint64_t rows = (VGSDF_TILE_PIXELS - 2) / w + 2;
-		if (rows * (w + 1) > delta_cap || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24))
+		if (!fits(w, 1) || (in->seg_off[g + 1] - in->seg_off[g]) >= (1u << 24))
 			return 2;
 		return 0;
 	};
+	b->span_list = span;
 	const char *ord = std::getenv("VGSDF_TILE_ORDER");
 	b->tile_order = ord ? std::atoi(ord) : 1;
 
@@ -275,10 +298,28 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 		std::vector<uint32_t> &gl = idx[cls];
 		const uint64_t first = ti;
 		if (b->tile_order != 0 && cls < 2)
-			std::stable_sort(gl.begin(), gl.end(), [&](uint32_t a, uint32_t c) { return nseg(a) > nseg(c); });
+		{
+			// weight of a glyph's workgroups: segments x tiles swept per staged chunk
+			static thread_local std::vector<uint64_t> wgt;
+			wgt.resize(n);
+			for (uint32_t g : gl) {
+				const uint64_t tiles_g = ((uint64_t)in->w[g] * in->h[g] + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
+				wgt[g] = (uint64_t)nseg(g) * std::min<uint64_t>(cls == 0 ? span_tiles(g) : 1, tiles_g);
+			}
+			std::stable_sort(gl.begin(), gl.end(), [&](uint32_t a, uint32_t c) { return wgt[a] > wgt[c]; });
+		}
+		// entries of glyph g: one per span of T tiles (T = 1 unless this is the span list's main class)
+		auto emit = [&](uint32_t g, auto &&push) {
+			const uint32_t px = in->w[g] * in->h[g];
+			const uint32_t T = cls == 0 ? span_tiles(g) : 1;
+			for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS * T) {
+				const uint32_t left = (px - p + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
+				push(make_uint2(g, span && cls == 0 ? (p | std::min(T, left)) : p));
+			}
+		};
 		uint64_t n_cls_tiles = 0;
 		for (uint32_t g : gl)
-			n_cls_tiles += ((uint64_t)in->w[g] * in->h[g] + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
+			emit(g, [&](uint2) { n_cls_tiles++; });
 		if (b->tile_order != 0 && cls < 2 && n_cls_tiles >= 64) {
 			// Workgroups are dealt round-robin over the 8 XCDs (position p runs on XCD p % 8, each
 			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
@@ -291,9 +332,7 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 				for (size_t k = 1; k < 8; k++)
 					if (queue[k].size() < queue[best].size())
 						best = k;
-				const uint32_t px = in->w[g] * in->h[g];
-				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
-					queue[best].push_back(make_uint2(g, p));
+				emit(g, [&](uint2 e) { queue[best].push_back(e); });
 			}
 			size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 			const uint64_t last = first + n_cls_tiles;
@@ -307,17 +346,15 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 					ht[ti++] = queue[src][taken[src]++];
 				}
 		} else {
-			for (uint32_t g : gl) {
-				const uint32_t px = in->w[g] * in->h[g];
-				for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS)
-					ht[ti++] = make_uint2(g, p);
-			}
+			for (uint32_t g : gl)
+				emit(g, [&](uint2 e) { ht[ti++] = e; });
 		}
 		if (cls == 0)
 			b->n_plain = (uint32_t)ti;
 		if (cls == 1)
 			b->n_main = (uint32_t)ti;
 	}
+	b->stats.n_tiles = ti; // workgroups actually launched (<= the 256-pixel tile count the list was sized for)
 	for (uint32_t g = 0; g < n; g++) {
 		hd[g].seg_off = in->seg_off[g];
 		hd[g].n_seg = in->seg_off[g + 1] - in->seg_off[g];
@@ -467,7 +504,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	if (n) {
 		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
 		uint2 *ht = (uint2 *)(hs + off_tiles);
-		build_descs_and_tiles(in, hd, ht, b);
+		build_descs_and_tiles(in, hd, ht, b, ctx->variant == 0 || ctx->variant == 50);
 		if (n_seg && !direct) {
 			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
 			std::memcpy(hs + off_sy, in->seg_sy, sizeof(double) * n_seg);
@@ -529,13 +566,18 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	// brute force.  1: everything brute.  A/B instances of the earlier generations: 22 / 23 packed
 	// grouped filter (1 px/lane) without / with per-wave culling; 2 / 3: the same with 2 px/lane;
 	// 12 / 13: scalar top-4 filter without / with culling; 30: bounded groups with the exact
-	// evaluation in every chunk; 45: same as 0; 31-39, 54-57, >= 100:
+	// evaluation in every chunk; 45: ... only where the byte is undecided (256-pixel tiles);
+	// 50: same as 0 (spans of up to 4 tiles); 31-39, 54-57, >= 100:
 	// timing-only ablations (wrong pixels)
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
 	// kernel id understood by vgsdf_launch_tiles
-	const int k_main = v == 0 ? 45 : (v == 13 ? 10 : (v == 3 ? 0 : v));
+	const int k_main = v == 0 ? 50 : (v == 13 ? 10 : (v == 3 ? 0 : v));
+	if (b->stats.n_tiles != 0 && (k_main == 50) != b->span_list) {
+		ctx->err = "vgsdf_batch_launch: the batch was uploaded for a different kernel variant (tile list layout)";
+		return VGSDF_E_ARG;
+	}
 	const int list_order = b->tile_order == 1;
 	int e = vgsdf_launch_tiles(k_main, list_order, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
 	                           b->d_out, ctx->stream);
@@ -807,8 +849,8 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16));
 	auto *hd = (vgsdf::GlyphDesc *)fe.h_stage.p;
 	auto *ht = (uint2 *)((uint8_t *)fe.h_stage.p + desc_bytes);
-	build_descs_and_tiles(&view, hd, ht, &b);
-	FE_TRY(hipMemcpyAsync(fe.descs_tiles.p, fe.h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
+	build_descs_and_tiles(&view, hd, ht, &b, ctx->variant == 0 || ctx->variant == 50);
+	FE_TRY(hipMemcpyAsync(fe.descs_tiles.p, fe.h_stage.p, desc_bytes + sizeof(uint2) * (size_t)b.stats.n_tiles, hipMemcpyHostToDevice, st));
 	b.d_glyphs = (vgsdf::GlyphDesc *)fe.descs_tiles.p;
 	b.d_tiles = (uint2 *)((uint8_t *)fe.descs_tiles.p + desc_bytes);
 	b.d_sx = (double *)fe.sx.p;
