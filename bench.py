@@ -26,7 +26,6 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VALU_PEAK_TF = 78.6     # datasheet FP64 vector (FMA = 2 flop); /2 without FMA contraction
 
 WORKLOADS = {
     # name: (font display name, [files relative to testdata/])
@@ -69,6 +68,14 @@ def traffic_bytes(workload, variant):
     try:
         d = json.loads((ROOT / "profiles" / "traffic.json").read_text())
         return d[f"{workload}:{variant}"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def pmc_value(workload, variant, key):
+    try:
+        d = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        return d[f"{workload}:{variant}"].get(key)
     except Exception:
         return None
 
@@ -171,7 +178,6 @@ def main():
     value = glyphs_total / elapsed
     kernel_s = kernel_ms_total * 1e-3 / steps
     alg_gbs = st["alg_bytes"] / kernel_s * 1e-9
-    flop = 16.0 * st["n_pairs"]
 
     out = {
         "metric": "glyphs/sec (SDF raster, Noto Sans Regular full BMP set)" if args.workload == "noto_regular"
@@ -207,21 +213,22 @@ def main():
             "unit": "GB/s",
             "frac": alg_gbs / HBM_PEAK_GBS,
             "traffic": traffic_bytes(args.workload, args.variant),
-            "kernel": ("sdf_tiles_pk<0,false,1> (small glyphs) / sdf_tiles_filtered<0,true> (large glyphs): the only "
-                       "kernels of a step" if args.variant == 0 else f"variant {args.variant}"),
+            "kernel": ("sdf_tiles_span<0>: the only kernel of a step (bounded groups over spans of tiles)"
+                       if args.variant == 0 else f"variant {args.variant}"),
             "kernel_ms_avg": kernel_s * 1e3,
             "alg_bytes_per_launch": st["alg_bytes"],
-            "note": "the path is FP64-VALU bound by construction (~250 flop/byte); see roofline_valu",
+            "note": "the path is VALU bound, not HBM bound (f32 bounds/filter per pixel x candidate segment, f64 only "
+                    "where the byte is undecided); see `valu`",
         },
-        "roofline_valu": {
-            "bound": "valu_f64",
-            "achieved": flop / kernel_s * 1e-12,
-            "peak": FP64_VALU_PEAK_TF / 2.0,
-            "unit": "TFLOP/s",
-            "frac": flop / kernel_s * 1e-12 / (FP64_VALU_PEAK_TF / 2.0),
-            "gpair_per_s": st["n_pairs"] / kernel_s * 1e-9,
-            "note": "algorithmic 16 flop per (pixel, segment) pair, brute-force count; peak = datasheet FP64 "
-                    "vector / 2 because bit-exactness forbids FMA contraction",
+        "valu": {
+            "insts_per_wave": pmc_value(args.workload, args.variant, "valu_insts_per_wave"),
+            "ginst_per_s_per_simd": pmc_value(args.workload, args.variant, "valu_ginst_per_s_per_simd"),
+            "issue_frac": pmc_value(args.workload, args.variant, "valu_issue_frac"),
+            "brute_pairs_per_s": st["n_pairs"] / kernel_s,
+            "note": "VALU instruction issue rate per SIMD from the PMC pass recorded in profiles/traffic.json (null if "
+                    "this workload/variant was not profiled) against the measured full-rate f32 issue of gfx950, 0.96 G "
+                    "inst/s/SIMD (tools/ubench/valu_rate.hip); brute_pairs_per_s = pixels x segments of the batch / "
+                    "kernel time, i.e. the rate a brute-force evaluation would need",
         },
         "host_stage_s": host_s,
     }

@@ -61,8 +61,21 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
               "our 8-B-per-lane loads are not separately calibrated)"]
     tj = dst / "traffic.json"
     d = json.loads(tj.read_text()) if tj.exists() else {}
-    d[f"{workload}:{variant}"] = {"bytes_per_launch": traffic, "fetch_kib": allc["FETCH_SIZE"],
-                                  "write_kib": allc["WRITE_SIZE"], "profile": f"profiles/{tag}_summary.md"}
+    ent = {"bytes_per_launch": traffic, "fetch_kib": allc["FETCH_SIZE"],
+           "write_kib": allc["WRITE_SIZE"], "profile": f"profiles/{tag}_summary.md"}
+    main = [r for r in stats if "sdf_tiles" in r["Name"]]
+    if main and all(k in allc for k in ("SQ_INSTS_VALU", "SQ_WAVES")):
+        # VALU issue rate per SIMD against the measured full-rate issue of gfx950 (tools/ubench/valu_rate.hip:
+        # v_fma/v_mul/v_sub_f32 2.5 cycles per wave64 instruction at 2.4 GHz = 0.96 G inst/s/SIMD; min/max/med3,
+        # f64 and transcendental instructions issue slower, so a mixed stream cannot reach 1.0)
+        avg_ns = max(float(r["AverageNs"]) for r in main)
+        ent["valu_insts_per_wave"] = allc["SQ_INSTS_VALU"] / allc["SQ_WAVES"]
+        ent["valu_ginst_per_s_per_simd"] = allc["SQ_INSTS_VALU"] / 1024.0 / avg_ns
+        ent["valu_issue_frac"] = ent["valu_ginst_per_s_per_simd"] / 0.96
+        lines += ["", f"VALU issue: {allc['SQ_INSTS_VALU']:.4g} instructions / 1024 SIMDs / {avg_ns:.0f} ns = "
+                  f"**{ent['valu_ginst_per_s_per_simd']:.3f} G inst/s/SIMD** = {ent['valu_issue_frac']:.2f} of the measured "
+                  f"full-rate f32 issue (0.96); {ent['valu_insts_per_wave']:.0f} VALU instructions per wave"]
+    d[f"{workload}:{variant}"] = ent
     tj.write_text(json.dumps(d, indent=1, sort_keys=True) + "\n")
 (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
 print("\n".join(lines))
