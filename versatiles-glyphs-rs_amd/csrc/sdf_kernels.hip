@@ -1416,10 +1416,11 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	#pragma unroll
 						for (int j = 0; j < 4; j++) {
 							const float ddx = rpx - axs[j], ddy = rpy - ays[j];
-							const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
-							D2[b * 4 + j] = d2;
-							dmin = min(dmin, __float_as_uint(d2)); // d2 >= +0: unsigned order is float order
+							D2[b * 4 + j] = __builtin_fmaf(ddy, ddy, ddx * ddx);
 						}
+						// d2 >= +0: unsigned order of the bits is float order; one v_min3_u32 per two groups
+						asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(__float_as_uint(D2[b * 4])), "v"(__float_as_uint(D2[b * 4 + 1])));
+						asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(__float_as_uint(D2[b * 4 + 2])), "v"(__float_as_uint(D2[b * 4 + 3])));
 					} else {
 	#pragma unroll
 						for (int j = 0; j < 4; j++)
@@ -1510,8 +1511,8 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					LB = LB > 0.0f ? LB : 0.0f;
 					LB = LB < 38.0f ? LB : 38.0f;
 					const float Uc = U < 38.0f ? U : 38.0f;
-					const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 1.0e-3f));
-					const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 1.0e-3f));
+					const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 2.0e-4f));
+					const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 2.0e-4f));
 					if (q_lo == q_hi) {
 						const int q = (int)q_lo;
 						b_in = (uint32_t)min(191 + q, 255);
@@ -1535,10 +1536,24 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					while (m) {
 						const uint32_t gq = (uint32_t)__builtin_ctz(m);
 						m &= m - 1;
-						const uint32_t je = gq * GRP + GRP < cnt ? gq * GRP + GRP : cnt;
-						for (uint32_t j = gq * GRP; j < je; j++) {
-							const float F = sc_filter(rpx, rpy, s_vx[j], s_vy[j], s_dx[j], s_dy[j], s_inv[j]);
-							if (!(F > Tk))
+						const float4 vxa = q_vx[2 * gq], vya = q_vy[2 * gq], dxa = q_dx[2 * gq], dya = q_dy[2 * gq], iva = q_inv[2 * gq];
+						const float4 vxb = q_vx[2 * gq + 1], vyb = q_vy[2 * gq + 1], dxb = q_dx[2 * gq + 1], dyb = q_dy[2 * gq + 1],
+						             ivb = q_inv[2 * gq + 1];
+						const float vxs[8] = {vxa.x, vxa.y, vxa.z, vxa.w, vxb.x, vxb.y, vxb.z, vxb.w};
+						const float vys[8] = {vya.x, vya.y, vya.z, vya.w, vyb.x, vyb.y, vyb.z, vyb.w};
+						const float dxs[8] = {dxa.x, dxa.y, dxa.z, dxa.w, dxb.x, dxb.y, dxb.z, dxb.w};
+						const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
+						const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
+						uint32_t hit = 0; // members at or below the threshold (padded records have F = 2e36)
+#pragma unroll
+						for (uint32_t j = 0; j < GRP; j++) {
+							const float F = sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]);
+							hit |= !(F > Tk) ? (1u << j) : 0u;
+						}
+						while (hit) {
+							const uint32_t j = gq * GRP + (uint32_t)__builtin_ctz(hit);
+							hit &= hit - 1;
+							if (j < cnt)
 								exact_lds(j);
 						}
 					}
