@@ -11,12 +11,13 @@
 // sqrt, round-half-away quantisation.  Winding sign is the order-independent sum the
 // reference builds with a sorted sweep (renderer_precise.rs:41-67).
 //
-// Mapping (MI355X): one 256-thread workgroup = 4 wave64 = one "tile" of 256 consecutive
-// OUTPUT bytes of one glyph bitmap (so stores are coalesced row-major), one pixel per
-// lane.  Segments are staged through LDS in SoA chunks with the per-segment invariants
-// (w-v, |w-v|^2) computed once at staging time; every lane then walks the chunk with
-// wave-uniform (broadcast) LDS reads.  The pair loop is FP64-VALU bound, not HBM bound
-// (≈16 flop per 32/(w*h) bytes): see DESIGN.md for the roofline.
+// Mapping (MI355X): a "tile" = 256 consecutive OUTPUT bytes of one glyph bitmap (stores are
+// coalesced row-major), one pixel per lane of a 256-thread workgroup (4 wave64).  Segments are
+// staged through LDS in chunks of 256.  The default kernel (sdf_tiles_span, at the end of this
+// file) sweeps up to 4 tiles of a glyph per staged chunk and looks, per pixel, only at the runs of
+// the outline that bounds cannot rule out; the earlier generations above it are kept for A/B
+// measurements and as independent bit-exact implementations in the tests.  The path is VALU bound,
+// not HBM bound: see DESIGN.md §4 for the algorithm, the exactness argument and the roofline.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
 }
 
 // ---------------------------------------------------------------------------------------
-// Variant 0 (default): filtered, single pass.  Same bytes as brute force, ~N/2 fewer exact
-// evaluations per pixel.
+// Variants 12 / 13 (first filtered generation, kept for A/B): single pass over ALL segments with
+// an f32 filter; same bytes as brute force.  Its exactness argument is shared by every later kernel.
 //
 //   filter  every (pixel, segment) pair is evaluated in f32 (9 VALU ops) with coordinates
 //           relative to the glyph origin.  The value F is packed with the segment's index
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__res
 }
 
 // ---------------------------------------------------------------------------------------
-// Variant 0 (default since the packed rewrite): same algorithm and the same exactness
+// Variants 22 / 23 (second generation, kept for A/B): same algorithm and the same exactness
 // argument as sdf_tiles_filtered, with the f32 filter evaluated for TWO segments per VALU
 // instruction (v_pk_add/mul/fma_f32 issue at the scalar rate on gfx950 — measured,
 // tools/ubench/valu_rate.hip — so the 9 filter ops cost 4.5 issue slots per segment).
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(TPB / PPL) void sdf_tiles_pk(const GlyphDesc *__res
 }
 
 // ---------------------------------------------------------------------------------------
-// Variant 30: bounded groups — the reference's "ask the R-tree for the segments near this pixel"
+// Variants 30 / 45 (third generation, 256-pixel tiles, kept for A/B): bounded groups — the reference's "ask the R-tree for the segments near this pixel"
 // (rtree_segments.rs:40-56) done the wave64 way.  Same staging, winding and exact evaluation as
 // above; what changes is which (pixel, segment) pairs the f32 filter looks at.
 //
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// Variant 0 (default): bounded groups over SPANS.  Same bounds, filter, bin decision and exact
+// Variant 0 = 50 (default): bounded groups over SPANS.  Same bounds, filter, bin decision and exact
 // fallback as sdf_tiles_hier<.., LAZY>; what changes is the unit of work of a workgroup: up to
 // SPAN = 4 consecutive 256-pixel tiles of ONE glyph.  A chunk of segments is staged (f64 loads,
 // f32 records, row crossings, group bounds) ONCE and then swept by the span's tiles one after the
@@ -1597,8 +1598,8 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 // ---------------------------------------------------------------------------------------
 extern "C" int vgsdf_filtered_delta_cap(void) { return vgsdf::DELTA_CAP; }
 
-// variant 0: filtered kernel; variant 1: brute force (also the fallback for tiles the host
-// routes there: glyphs too wide for the winding histogram, or with >= 2^24 segments).
+// variant ids: see vgsdf_batch_launch (vgsdf_device.cpp).  1 = brute force, also the fallback for the
+// tiles the host routes there: glyphs too wide for the winding histogram, or with >= 2^24 segments.
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
                                   const uint2 *tiles, uint32_t n_tiles_in, const double *sx,
                                   const double *sy, const double *ex, const double *ey, uint8_t *out,
@@ -1640,38 +1641,15 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_HIER(1, false);
 	else if (variant == 35) // timing-only: no exact evaluation
 		VG_LAUNCH_HIER(4, false);
-	else if (variant >= 100) { // timing-only ablations 100 + mask
-		switch (variant - 100) {
-		case 1: VG_LAUNCH_FILTERED(1, true); break;
-		case 2: VG_LAUNCH_FILTERED(2, true); break;
-		case 4: VG_LAUNCH_FILTERED(4, true); break;
-		case 6: VG_LAUNCH_FILTERED(6, true); break;
-		case 8: VG_LAUNCH_FILTERED(8, true); break;
-		case 36: VG_LAUNCH_FILTERED(36, true); break;
-		case 16: VG_LAUNCH_FILTERED(16, true); break;
-		case 23: VG_LAUNCH_FILTERED(23, true); break;
-		case 22: VG_LAUNCH_FILTERED(22, true); break;
-		default: VG_LAUNCH_FILTERED(0, true); break;
-		}
-	} else if (variant == 2) // packed filter, no culling
-		VG_LAUNCH_PK(0, false, 2);
-	else if (variant == 22) // packed filter, 1 pixel per lane, no culling (A/B)
+	else if (variant == 22) // earlier generation: packed filter, grouped selection (A/B)
 		VG_LAUNCH_PK(0, false, 1);
-	else if (variant == 23)
+	else if (variant == 23) // ... with per-wave culling
 		VG_LAUNCH_PK(0, true, 1);
-	else if (variant == 12) // previous generation: scalar filter, no culling (A/B)
+	else if (variant == 12) // earlier generation: scalar filter, top-4 keys (A/B)
 		VG_LAUNCH_FILTERED(0, false);
-	else if (variant == 10)
+	else if (variant == 10) // ... with per-wave culling
 		VG_LAUNCH_FILTERED(0, true);
-	else if (variant == 54)
-		VG_LAUNCH_PK(4, false, 2);
-	else if (variant == 55)
-		VG_LAUNCH_PK(4, false, 1);
-	else if (variant == 56)
-		VG_LAUNCH_PK(36, false, 2);
-	else if (variant == 57)
-		VG_LAUNCH_PK(36, false, 1);
 	else
-		VG_LAUNCH_PK(0, true, 2);
+		return (int)hipErrorInvalidValue;
 	return (int)hipGetLastError();
 }

@@ -562,18 +562,16 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_E_ARG;
 	}
 	(void)hipSetDevice(ctx->device);
-	// variant 0 (default): bounded-group kernel for every tile the winding histogram fits; misfits:
-	// brute force.  1: everything brute.  A/B instances of the earlier generations: 22 / 23 packed
-	// grouped filter (1 px/lane) without / with per-wave culling; 2 / 3: the same with 2 px/lane;
-	// 12 / 13: scalar top-4 filter without / with culling; 30: bounded groups with the exact
-	// evaluation in every chunk; 45: ... only where the byte is undecided (256-pixel tiles);
-	// 50: same as 0 (spans of up to 4 tiles); 31-39, 54-57, >= 100:
-	// timing-only ablations (wrong pixels)
+	// variant 0 (default) = 50: bounded groups over spans of tiles; misfits: brute force.
+	// 1: everything brute.  Earlier generations kept for A/B (all bit-exact): 45 bounded groups on
+	// 256-pixel tiles, 30 ... with the exact evaluation in every chunk, 22 / 23 packed grouped filter
+	// without / with per-wave culling, 12 / 13 scalar top-4 filter without / with culling.
+	// 31-35: timing-only ablations of 30 (wrong pixels).
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
 	// kernel id understood by vgsdf_launch_tiles
-	const int k_main = v == 0 ? 50 : (v == 13 ? 10 : (v == 3 ? 0 : v));
+	const int k_main = v == 0 ? 50 : (v == 13 ? 10 : v);
 	if (b->stats.n_tiles != 0 && (k_main == 50) != b->span_list) {
 		ctx->err = "vgsdf_batch_launch: the batch was uploaded for a different kernel variant (tile list layout)";
 		return VGSDF_E_ARG;
