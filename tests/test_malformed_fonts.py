@@ -1,0 +1,81 @@
+"""Robustness of the two TrueType readers (the product's C++ `vg::Face`, the oracle's C reader)
+against damaged input: truncated files and random byte flips of a real font.  ttf-parser, which
+the reference uses (`file_entry.rs:48`), answers such input with an error or with missing glyphs,
+never with a crash; here every mutated font is pushed through parse -> cmap -> outline -> flatten ->
+bbox (+ PBF encode with the dummy raster) in a CHILD process whose exit status is checked."""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+CHILD = r"""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(sys.argv[1]); which = sys.argv[2]; seed = int(sys.argv[3])
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from conftest import load_product, FIRA
+data = Path(FIRA).read_bytes()
+rng = np.random.default_rng(seed)
+def mutants():
+    yield data  # control
+    for cut in (0, 3, 11, 12, 100, 300, 1000, 5000, 20000, len(data) // 2, len(data) - 1):
+        yield data[:cut]
+    # damage concentrated in the table directory / head / maxp / cmap / loca region and spread over the file
+    for _ in range(60):
+        b = bytearray(data)
+        hi = (400, 4000, 60000, len(b))[int(rng.integers(0, 4))]
+        for pos in rng.integers(0, hi, int(rng.integers(1, 24))):
+            b[int(pos)] = int(rng.integers(0, 256))
+        yield bytes(b)
+ok = bad = 0
+if which == "product":
+    vg = load_product()
+    r = vg.Renderer.new_dummy()
+    for i, m in enumerate(mutants()):
+        mgr = vg.FontManager(False)
+        try:
+            fid = mgr.add_font_data(f"Mutant {i}", m)
+        except RuntimeError:
+            bad += 1
+            continue
+        rec = mgr.record_outlines(fid)
+        assert len(rec["cmd_off"]) == len(rec["ids"]) + 1
+        w = vg.DummyWriter()
+        try:
+            mgr.render_glyphs(w, r)
+        except RuntimeError:
+            pass
+        ok += 1
+else:
+    from oracle import oracle as O
+    import tempfile, os
+    for i, m in enumerate(mutants()):
+        with tempfile.NamedTemporaryFile(suffix=".ttf", delete=False) as fh:
+            fh.write(m)
+        try:
+            try:
+                f = O.Font(fh.name)
+            except Exception:
+                bad += 1
+                continue
+            for cp in f.codepoints()[:400]:
+                f.prepare_glyph(int(cp))
+            ok += 1
+        finally:
+            os.unlink(fh.name)
+assert ok >= 1, "the undamaged control font must load"
+print(f"{which}: {ok} loaded, {bad} rejected")
+"""
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_damaged_fonts_never_crash(which, seed):
+    p = subprocess.run([sys.executable, "-c", CHILD, str(ROOT), which, str(seed)], capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, f"child died with {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+    assert "loaded" in p.stdout

@@ -1,0 +1,11 @@
+#!/bin/bash
+# CPU-only sanitizer pass: the host C++ (TrueType reader, flattening, batching, PBF, C API) built with
+# ASan + UBSan, driven by the CPU test files that exercise it, and the oracle's C under the same.
+set -e
+cd "$(dirname "$0")/.."
+make -C versatiles-glyphs-rs_amd asan > /dev/null
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
+  VGSDF_LIB=$PWD/versatiles-glyphs-rs_amd/build/asan/libvgsdf.so \
+  python -m pytest tests/test_host_facade.py tests/test_host_vs_oracle.py tests/test_capi_exports.py \
+    "tests/test_malformed_fonts.py::test_damaged_fonts_never_crash" -x -q -k "not 1-oracle and not 2-oracle"
