@@ -16,7 +16,7 @@ for cp in cps:
         jobs.append(r)
 ctx = vg.SdfContext(0)
 ctx.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-for k in (1, 2, 4, 8):
+for k in ((1, 2, 4, 8) if len(sys.argv) < 3 else (int(sys.argv[2]),)):
     batch = vg.make_batch([(s, i.x0, i.y0, i.w, i.h) for i, s in jobs] * k)
     db = ctx.upload(batch)
     db.time(3)

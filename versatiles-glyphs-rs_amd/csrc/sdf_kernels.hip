@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				mf = (float)m * 1.000001f;               // round up
 				mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
 				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
-				if (vy != wy) {
+				if (!(ABL & 1) && vy != wy) {
 					const bool up = vy < wy;
 					const double lo = up ? vy : wy, hi = up ? wy : vy;
 					const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
@@ -1404,7 +1404,9 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 
 			// ---- phase 1: candidate groups of this lane ----
 			uint32_t cand = n_groups >= 32 ? 0xFFFFFFFFu : ((1u << n_groups) - 1u);
-			if (bounded) {
+			if (ABL & 32)
+				cand &= 1u;
+			if (bounded && !(ABL & 32)) {
 				float D2[NGRP];
 				uint32_t dmin = __float_as_uint(ub2);
 				const float4 *gx4 = reinterpret_cast<const float4 *>(s_gx), *gy4 = reinterpret_cast<const float4 *>(s_gy);
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			// ---- phase 2: smallest f32 filter value over the lane's candidate groups (F >= +0: unsigned
 			// order of the bits is float order) ----
 			uint32_t k1 = 0xFFFFFFFFu;
-			if (sane) {
+			if (sane && !(ABL & 2)) {
 				uint32_t m = cand;
 				while (m) {
 					const uint32_t gq = (uint32_t)__builtin_ctz(m);
@@ -1523,7 +1525,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					const float uf = U * (1.0f + 1.0f / 1048576.0f);
 					ub2 = uf < ub2 ? uf : ub2; // bounds the later chunks' candidates too
 				}
-				if (!decided) {
+				if (!decided && !(ABL & 4)) {
 					// Rescan of the lane's candidate groups against a threshold Tk with L(Tk) > U (L increasing
 					// above it): fixed-point iteration for the crossing, pushed up, then VERIFIED; if the check
 					// fails nothing is excluded (Tk = inf).  Everything at or below Tk is evaluated exactly.
@@ -1629,6 +1631,16 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_HIER(0, false);
 	else if (variant == 50) // bounded groups over spans of up to 4 tiles (tile list: first pixel | T)
 		VG_LAUNCH_SPAN(0);
+	else if (variant == 51) // timing-only ablations of the span kernel: no phase 2 (and nothing after it)
+		VG_LAUNCH_SPAN(2);
+	else if (variant == 52) // ... no exact fallback
+		VG_LAUNCH_SPAN(4);
+	else if (variant == 53) // ... no phase 1 (one candidate group), no phase 2
+		VG_LAUNCH_SPAN(34);
+	else if (variant == 54) // ... staging only, without the row crossings
+		VG_LAUNCH_SPAN(35);
+	else if (variant == 55) // ... no row crossings
+		VG_LAUNCH_SPAN(1);
 	else if (variant == 45) // bounded groups, exact evaluation only where the byte is undecided
 		VG_LAUNCH_HIER(0, true);
 	else if (variant == 31) // timing-only: no phase 2

@@ -504,7 +504,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	if (n) {
 		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
 		uint2 *ht = (uint2 *)(hs + off_tiles);
-		build_descs_and_tiles(in, hd, ht, b, ctx->variant == 0 || ctx->variant == 50);
+		build_descs_and_tiles(in, hd, ht, b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 59));
 		if (n_seg && !direct) {
 			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
 			std::memcpy(hs + off_sy, in->seg_sy, sizeof(double) * n_seg);
@@ -566,13 +566,13 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	// 1: everything brute.  Earlier generations kept for A/B (all bit-exact): 45 bounded groups on
 	// 256-pixel tiles, 30 ... with the exact evaluation in every chunk, 22 / 23 packed grouped filter
 	// without / with per-wave culling, 12 / 13 scalar top-4 filter without / with culling.
-	// 31-35: timing-only ablations of 30 (wrong pixels).
+	// 31-35 / 51-55: timing-only ablations of 30 / 50 (wrong pixels).
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
 	// kernel id understood by vgsdf_launch_tiles
 	const int k_main = v == 0 ? 50 : (v == 13 ? 10 : v);
-	if (b->stats.n_tiles != 0 && (k_main == 50) != b->span_list) {
+	if (b->stats.n_tiles != 0 && (k_main >= 50 && k_main <= 59) != b->span_list) {
 		ctx->err = "vgsdf_batch_launch: the batch was uploaded for a different kernel variant (tile list layout)";
 		return VGSDF_E_ARG;
 	}
@@ -847,7 +847,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16));
 	auto *hd = (vgsdf::GlyphDesc *)fe.h_stage.p;
 	auto *ht = (uint2 *)((uint8_t *)fe.h_stage.p + desc_bytes);
-	build_descs_and_tiles(&view, hd, ht, &b, ctx->variant == 0 || ctx->variant == 50);
+	build_descs_and_tiles(&view, hd, ht, &b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 59));
 	FE_TRY(hipMemcpyAsync(fe.descs_tiles.p, fe.h_stage.p, desc_bytes + sizeof(uint2) * (size_t)b.stats.n_tiles, hipMemcpyHostToDevice, st));
 	b.d_glyphs = (vgsdf::GlyphDesc *)fe.descs_tiles.p;
 	b.d_tiles = (uint2 *)((uint8_t *)fe.descs_tiles.p + desc_bytes);
