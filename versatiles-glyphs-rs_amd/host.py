@@ -222,7 +222,7 @@ class FontManager:
 
     def render_glyphs(self, writer, renderer: Renderer, font_id: str = None, block_starts=None):
         """FontManager::render_glyphs(&mut writer, &renderer).  `writer` needs
-        write_directory(path) and write_file(path, bytes).  With font_id + block_starts only
+        write_directory(path) and write_file(path, bytes), or is None.  With font_id + block_starts only
         that shard of the (font, block) task list is rendered."""
         errors = []
 
@@ -237,7 +237,9 @@ class FontManager:
                 errors.append(e)
                 return 1
 
-        ccb = WRITE_CB(cb)
+        # writer=None: NULL sink (the bytes are produced and counted, see timings()["pbf_bytes"], but not
+        # handed to Python) -- what a native caller's in-memory writer costs
+        ccb = WRITE_CB(cb) if writer is not None else C.cast(None, WRITE_CB)
         if block_starts is None:
             rc = _L().vg_manager_render_glyphs(self._h, renderer._h, ccb, None)
         else:
