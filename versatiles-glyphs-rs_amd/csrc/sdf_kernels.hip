@@ -1264,8 +1264,11 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	__shared__ __attribute__((aligned(16))) float s_gx[NGRP], s_gy[NGRP], s_gr[NGRP]; // anchor, radius
 	__shared__ float st_ub2[SPAN_TILES * TPB];    // per pixel: upper bound of the squared distance so far
 	__shared__ uint16_t st_byte[SPAN_TILES * TPB]; // per pixel: byte if inside (low), byte if outside (high)
+	constexpr uint32_t QCAP = 256;                 // pooled (pixel, group) pairs per wave and sweep; beyond: per-lane walk
+	__shared__ uint16_t q_pair[TPB / 64][QCAP];    // (lane << 5) | group
+	__shared__ uint32_t q_min[TPB / 64][64];       // per pixel of the wave: smallest filter value (bits)
 
-	const uint32_t tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
 	const uint2 t = tiles[tile];
 	const GlyphDesc g = glyphs[t.x];
@@ -1377,7 +1380,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				const bool empty = gb >= cnt;
 				s_gx[tid / GRP] = empty ? 1.0e18f : ax;
 				s_gy[tid / GRP] = empty ? 1.0e18f : ay;
-				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL;
+				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL * 1.004f; // 1.004: see phase 1
 			}
 		}
 		__syncthreads();
@@ -1407,46 +1410,54 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			if (ABL & 32)
 				cand &= 1u;
 			if (bounded && !(ABL & 32)) {
-				float D2[NGRP];
+				// D_g^2 of two groups per register, upper 16 bits of each float (truncation: the stored value
+				// is <= the true one; the high half read as a float is < true * (1 + 2^-7)): keeps the kernel
+				// inside the 128-VGPR budget of 4 waves per SIMD.  The test below inflates U + r_g by 1.004
+				// (> sqrt(1 + 2^-7)), so every true candidate still passes.
+				uint32_t D2p[NGRP / 2];
 				uint32_t dmin = __float_as_uint(ub2);
 				const float4 *gx4 = reinterpret_cast<const float4 *>(s_gx), *gy4 = reinterpret_cast<const float4 *>(s_gy);
 				const float4 *gr4 = reinterpret_cast<const float4 *>(s_gr);
-	#pragma unroll
+#pragma unroll
 				for (uint32_t b = 0; b < NGRP / 4; b++) {
 					if (b * 4 < n_groups) {
 						const float4 ax = gx4[b], ay = gy4[b];
 						const float axs[4] = {ax.x, ax.y, ax.z, ax.w}, ays[4] = {ay.x, ay.y, ay.z, ay.w};
-	#pragma unroll
+						uint32_t d2[4];
+#pragma unroll
 						for (int j = 0; j < 4; j++) {
 							const float ddx = rpx - axs[j], ddy = rpy - ays[j];
-							D2[b * 4 + j] = __builtin_fmaf(ddy, ddy, ddx * ddx);
+							d2[j] = __float_as_uint(__builtin_fmaf(ddy, ddy, ddx * ddx));
 						}
 						// d2 >= +0: unsigned order of the bits is float order; one v_min3_u32 per two groups
-						asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(__float_as_uint(D2[b * 4])), "v"(__float_as_uint(D2[b * 4 + 1])));
-						asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(__float_as_uint(D2[b * 4 + 2])), "v"(__float_as_uint(D2[b * 4 + 3])));
+						asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(d2[0]), "v"(d2[1]));
+						asm("v_min3_u32 %0, %1, %2, %3" : "=v"(dmin) : "v"(dmin), "v"(d2[2]), "v"(d2[3]));
+						D2p[b * 2] = __builtin_amdgcn_perm(d2[1], d2[0], 0x07060302u);     // hi16(d2[1]) : hi16(d2[0])
+						D2p[b * 2 + 1] = __builtin_amdgcn_perm(d2[3], d2[2], 0x07060302u);
 					} else {
-	#pragma unroll
-						for (int j = 0; j < 4; j++)
-							D2[b * 4 + j] = __builtin_inff();
+						D2p[b * 2] = D2p[b * 2 + 1] = 0x7F807F80u; // +inf : +inf
 					}
 				}
 				ub2 = __uint_as_float(dmin);
 				float U = (__builtin_sqrtf(ub2) * INFL + pad) * INFL;
 				U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
-				// One bit per group, 3 VALU ops each: tt = U + r_g, diff = tt^2 - D_g^2 (sign bit set <=> not
-				// a candidate; -inf for the groups past n_groups), shifted in with v_alignbit.  The bits
-				// arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
+				const float Ui = U * 1.004f; // s_gr is stored with the same factor
+				// One bit per group, 3-4 VALU ops each: tt = (U + r_g) 1.004, diff = tt^2 - D_g^2 (sign bit set
+				// <=> not a candidate; -inf for the groups past n_groups), shifted in with v_alignbit.  The
+				// bits arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
 				uint32_t rej = 0xFFFFFFFFu;
-	#pragma unroll
+#pragma unroll
 				for (uint32_t b = 0; b < NGRP / 4; b++) {
 					float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 					if (b * 4 < n_groups)
 						r = gr4[b];
 					const float rs[4] = {r.x, r.y, r.z, r.w};
-	#pragma unroll
+#pragma unroll
 					for (int j = 0; j < 4; j++) {
-						const float tt = U + rs[j];
-						const float diff = __builtin_fmaf(tt, tt, -D2[b * 4 + j]);
+						const uint32_t pk = D2p[b * 2 + j / 2];
+						const float d2 = __uint_as_float((j & 1) ? pk : (pk << 16));
+						const float tt = Ui + rs[j];
+						const float diff = __builtin_fmaf(tt, tt, -d2);
 						rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(diff), 31); // (rej << 1) | sign(diff)
 					}
 				}
@@ -1457,28 +1468,71 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			// ---- phase 2: smallest f32 filter value over the lane's candidate groups (F >= +0: unsigned
 			// order of the bits is float order) ----
 			uint32_t k1 = 0xFFFFFFFFu;
-			if (sane && !(ABL & 2)) {
-				uint32_t m = cand;
-				while (m) {
-					const uint32_t gq = (uint32_t)__builtin_ctz(m);
-					m &= m - 1;
-					const float4 vxa = q_vx[2 * gq], vya = q_vy[2 * gq], dxa = q_dx[2 * gq], dya = q_dy[2 * gq], iva = q_inv[2 * gq];
-					const float4 vxb = q_vx[2 * gq + 1], vyb = q_vy[2 * gq + 1], dxb = q_dx[2 * gq + 1], dyb = q_dy[2 * gq + 1],
-					             ivb = q_inv[2 * gq + 1];
-					const float vxs[8] = {vxa.x, vxa.y, vxa.z, vxa.w, vxb.x, vxb.y, vxb.z, vxb.w};
-					const float vys[8] = {vya.x, vya.y, vya.z, vya.w, vyb.x, vyb.y, vyb.z, vyb.w};
-					const float dxs[8] = {dxa.x, dxa.y, dxa.z, dxa.w, dxb.x, dxb.y, dxb.z, dxb.w};
-					const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
-					const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
-					uint32_t fb[GRP];
+			auto group_min = [&](uint32_t acc, uint32_t gq, float qx, float qy) { // min(acc, F of the 8 members of group gq)
+				// two halves of 4 records: 20 + 4 live values instead of 40 + 8 (the kernel sits at the 128-VGPR
+				// limit of 4 waves per SIMD; spills would go to scratch, i.e. to memory)
 #pragma unroll
-					for (uint32_t j = 0; j < GRP; j++)
-						fb[j] = __float_as_uint(sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]));
+				for (uint32_t hq = 0; hq < 2; hq++) {
+					const float4 vx4 = q_vx[2 * gq + hq], vy4 = q_vy[2 * gq + hq], dx4 = q_dx[2 * gq + hq], dy4 = q_dy[2 * gq + hq],
+					             iv4 = q_inv[2 * gq + hq];
+					const uint32_t f0 = __float_as_uint(sc_filter(qx, qy, vx4.x, vy4.x, dx4.x, dy4.x, iv4.x));
+					const uint32_t f1 = __float_as_uint(sc_filter(qx, qy, vx4.y, vy4.y, dx4.y, dy4.y, iv4.y));
+					const uint32_t f2 = __float_as_uint(sc_filter(qx, qy, vx4.z, vy4.z, dx4.z, dy4.z, iv4.z));
+					const uint32_t f3 = __float_as_uint(sc_filter(qx, qy, vx4.w, vy4.w, dx4.w, dy4.w, iv4.w));
 					uint32_t mn;
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(k1), "v"(fb[0]), "v"(fb[1]));
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[2]), "v"(fb[3]));
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[4]), "v"(fb[5]));
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(k1) : "v"(mn), "v"(fb[6]), "v"(fb[7]));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(acc), "v"(f0), "v"(f1));
+					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc) : "v"(mn), "v"(f2), "v"(f3));
+					if (hq == 0)
+						__builtin_amdgcn_sched_barrier(0);
+				}
+				return acc;
+			};
+			if (sane && !(ABL & 2)) {
+				if (o >= npix)
+					cand = 0; // padding lanes of the last tile own no pixel
+				// The lanes of a wave hold very different numbers of candidate groups (mean 1.7 per chunk,
+				// busiest lane 4-5).  Instead of every lane walking its own list while the others idle, the
+				// wave pools its (pixel, group) pairs in LDS and deals them out evenly: 64 pairs per round,
+				// results merged with ds_min_u32 on the owning pixel's slot.
+				const uint32_t c = (uint32_t)__builtin_popcount(cand);
+				uint32_t incl = c; // inclusive prefix sum over the wave: DPP row shifts + row broadcasts
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false); // row_shr:1
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false); // row_shr:2
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false); // row_shr:4
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false); // row_shr:8
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				if (total <= QCAP && !(ABL & 64)) {
+					uint32_t off = incl - c;
+					q_min[wv][lane] = 0xFFFFFFFFu;
+					uint32_t m = cand;
+					while (m) {
+						q_pair[wv][off++] = (uint16_t)((lane << 5) | (uint32_t)__builtin_ctz(m));
+						m &= m - 1;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					for (uint32_t base = 0; base < total; base += 64) {
+						const uint32_t idx = base + lane;
+						const bool valid = idx < total;
+						const uint32_t e = q_pair[wv][valid ? idx : base];
+						const uint32_t src = e >> 5;
+						const float qx = __shfl(rpx, (int)src), qy = __shfl(rpy, (int)src);
+						const uint32_t mn = group_min(0xFFFFFFFFu, e & 31u, qx, qy);
+						if (valid)
+							atomicMin(&q_min[wv][src], mn);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					k1 = q_min[wv][lane];
+				} else {
+					uint32_t m = cand;
+					while (m) {
+						const uint32_t gq = (uint32_t)__builtin_ctz(m);
+						m &= m - 1;
+						k1 = group_min(k1, gq, rpx, rpy);
+					}
 				}
 			}
 
@@ -1539,19 +1593,16 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					while (m) {
 						const uint32_t gq = (uint32_t)__builtin_ctz(m);
 						m &= m - 1;
-						const float4 vxa = q_vx[2 * gq], vya = q_vy[2 * gq], dxa = q_dx[2 * gq], dya = q_dy[2 * gq], iva = q_inv[2 * gq];
-						const float4 vxb = q_vx[2 * gq + 1], vyb = q_vy[2 * gq + 1], dxb = q_dx[2 * gq + 1], dyb = q_dy[2 * gq + 1],
-						             ivb = q_inv[2 * gq + 1];
-						const float vxs[8] = {vxa.x, vxa.y, vxa.z, vxa.w, vxb.x, vxb.y, vxb.z, vxb.w};
-						const float vys[8] = {vya.x, vya.y, vya.z, vya.w, vyb.x, vyb.y, vyb.z, vyb.w};
-						const float dxs[8] = {dxa.x, dxa.y, dxa.z, dxa.w, dxb.x, dxb.y, dxb.z, dxb.w};
-						const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
-						const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
-						uint32_t hit = 0; // members at or below the threshold (padded records have F = 2e36)
-#pragma unroll
-						for (uint32_t j = 0; j < GRP; j++) {
-							const float F = sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]);
-							hit |= !(F > Tk) ? (1u << j) : 0u;
+						// members at or below the threshold (padded records have F = 2e36), 4 records at a time
+						uint32_t hit = 0;
+#pragma unroll 1
+						for (uint32_t hq = 0; hq < 2; hq++) {
+							const float4 vx4 = q_vx[2 * gq + hq], vy4 = q_vy[2 * gq + hq], dx4 = q_dx[2 * gq + hq], dy4 = q_dy[2 * gq + hq],
+							             iv4 = q_inv[2 * gq + hq];
+							hit |= !(sc_filter(rpx, rpy, vx4.x, vy4.x, dx4.x, dy4.x, iv4.x) > Tk) ? (1u << (4 * hq)) : 0u;
+							hit |= !(sc_filter(rpx, rpy, vx4.y, vy4.y, dx4.y, dy4.y, iv4.y) > Tk) ? (2u << (4 * hq)) : 0u;
+							hit |= !(sc_filter(rpx, rpy, vx4.z, vy4.z, dx4.z, dy4.z, iv4.z) > Tk) ? (4u << (4 * hq)) : 0u;
+							hit |= !(sc_filter(rpx, rpy, vx4.w, vy4.w, dx4.w, dy4.w, iv4.w) > Tk) ? (8u << (4 * hq)) : 0u;
 						}
 						while (hit) {
 							const uint32_t j = gq * GRP + (uint32_t)__builtin_ctz(hit);
@@ -1641,6 +1692,8 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_SPAN(35);
 	else if (variant == 55) // ... no row crossings
 		VG_LAUNCH_SPAN(1);
+	else if (variant == 56) // A/B: per-lane candidate walk instead of the pooled pairs
+		VG_LAUNCH_SPAN(64);
 	else if (variant == 45) // bounded groups, exact evaluation only where the byte is undecided
 		VG_LAUNCH_HIER(0, true);
 	else if (variant == 31) // timing-only: no phase 2
