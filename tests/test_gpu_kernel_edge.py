@@ -135,6 +135,29 @@ def test_finely_flattened_outlines(oracle, vg, ctx):
     run_both(oracle, vg, ctx, glyphs)
 
 
+def test_tall_glyphs_with_localised_chunks(oracle, vg, ctx):
+    """tall bitmaps made of small finely flattened rings stacked vertically (and horizontally): each
+    chunk of 256 segments is compact, so the default kernel skips most chunks per span by their boxes;
+    rings straddling chunk and row-band boundaries, winding through skipped chunks' neighbours"""
+    rng = np.random.default_rng(5)
+    glyphs = []
+    for n_rings, n_pts, vertical in ((7, 300, True), (5, 513, True), (6, 256, False), (9, 130, True)):
+        segs = []
+        for k in range(n_rings):
+            c = (8.0 + rng.uniform(-1, 1), 10.0 + 17.0 * k) if vertical else (10.0 + 17.0 * k, 8.0 + rng.uniform(-1, 1))
+            a = np.linspace(0, 2 * np.pi, n_pts, endpoint=False)
+            r = 5.0 * (1 + 0.25 * np.sin(3 * a + k))
+            pts = np.stack([c[0] + r * np.cos(a), c[1] + r * np.sin(a)], 1)
+            segs.append(ring(pts if k % 2 == 0 else pts[::-1]))
+            if k == 2:  # a nested ring inside ring 2 (winding 0 / 2 depending on orientation)
+                segs.append(ring(np.stack([c[0] + 2 * np.cos(a[::4]), c[1] + 2 * np.sin(a[::4])], 1)))
+        segs = np.concatenate(segs)
+        lo = np.floor(segs[:, [0, 1]].min(0)).astype(int) - 3
+        hi = np.ceil(segs[:, [0, 1]].max(0)).astype(int) + 3
+        glyphs.append((segs, int(lo[0]), int(lo[1]), int(hi[0] - lo[0]), int(hi[1] - lo[1])))
+    run_both(oracle, vg, ctx, glyphs)
+
+
 def test_wide_and_thin_rects(oracle, vg, ctx):
     rng = np.random.default_rng(3)
     wide = ring(np.stack([np.linspace(5, 1500, 60), 6 + 3 * np.sin(np.linspace(0, 20, 60))], 1).tolist()

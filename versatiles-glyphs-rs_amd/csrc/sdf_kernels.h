@@ -28,4 +28,10 @@ extern "C" int vgsdf_filtered_delta_cap(void);
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
                                   const uint2 *tiles, uint32_t n_tiles, const double *sx,
                                   const double *sy, const double *ex, const double *ey, uint8_t *out,
-                                  hipStream_t stream);
+                                  const void *boxes, hipStream_t stream);
+
+// chunk boxes of a resident batch (sdf_chunk_boxes): table size, and the preparation launch.  `boxes`
+// may be NULL in vgsdf_launch_tiles (no chunk is skipped then); only the span kernel reads it.
+extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs);
+extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t n_glyphs, const double *sx, const double *sy,
+                                        const double *ex, const double *ey, void *boxes, hipStream_t stream);

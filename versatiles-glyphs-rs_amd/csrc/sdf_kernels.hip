@@ -1231,6 +1231,61 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restric
 }
 
 // ---------------------------------------------------------------------------------------
+// Chunk boxes (batch preparation, run once per resident batch): the bounding box of every chunk
+// of 256 consecutive segments of a glyph, in f32 relative to the glyph origin (x0, y0).  The span
+// kernel reads one float4 per chunk and skips chunks that can neither cross its sample rows nor
+// hold a segment within reach of its pixels: a glyph with a long segment list (Noto Sans has one
+// with 4368 segments = 18 chunks) no longer drags every tile through every chunk, and its chain
+// of chunks stops setting the makespan of a small batch.
+// Index of chunk c of glyph g: (seg_off[g] >> 8) + g + c — unique for a monotone seg_off, so no
+// offset table is needed; the table has (total segments >> 8) + n_glyphs + 1 entries.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t chunk_box_index(uint32_t seg_off, uint32_t glyph, uint32_t c)
+{
+	return (seg_off >> 8) + glyph + c;
+}
+
+__global__ __launch_bounds__(64) void sdf_chunk_boxes(const GlyphDesc *__restrict__ glyphs, uint32_t n_glyphs,
+                                                      const double *__restrict__ seg_sx,
+                                                      const double *__restrict__ seg_sy,
+                                                      const double *__restrict__ seg_ex,
+                                                      const double *__restrict__ seg_ey, float4 *__restrict__ boxes)
+{
+	const uint32_t gi = blockIdx.x, lane = threadIdx.x;
+	if (gi >= n_glyphs)
+		return;
+	const GlyphDesc g = glyphs[gi];
+	for (uint32_t c0 = 0, c = 0; c0 < g.n_seg; c0 += FCHUNK, c++) {
+		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
+		float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
+		bool bad = false;
+		for (uint32_t i = lane; i < cnt; i += 64) {
+			const uint32_t s = g.seg_off + c0 + i;
+			const double rvx = seg_sx[s] - (double)g.x0, rvy = seg_sy[s] - (double)g.y0;
+			const double rwx = seg_ex[s] - (double)g.x0, rwy = seg_ey[s] - (double)g.y0;
+			const float a = (float)rvx, b = (float)rvy, cx = (float)rwx, d = (float)rwy;
+			bad |= !(fabsf(a) < 3.0e38f) || !(fabsf(b) < 3.0e38f) || !(fabsf(cx) < 3.0e38f) || !(fabsf(d) < 3.0e38f);
+			x0 = fminf(x0, fminf(a, cx));
+			x1 = fmaxf(x1, fmaxf(a, cx));
+			y0 = fminf(y0, fminf(b, d));
+			y1 = fmaxf(y1, fmaxf(b, d));
+		}
+		for (int sh = 32; sh > 0; sh >>= 1) {
+			x0 = fminf(x0, __shfl_xor(x0, sh));
+			y0 = fminf(y0, __shfl_xor(y0, sh));
+			x1 = fmaxf(x1, __shfl_xor(x1, sh));
+			y1 = fmaxf(y1, __shfl_xor(y1, sh));
+		}
+		const bool any_bad = __any(bad);
+		if (lane == 0) {
+			// non-finite coordinates: a box that contains everything (the chunk is never skipped)
+			const float inf = __builtin_inff();
+			boxes[chunk_box_index(g.seg_off, gi, c)] = any_bad ? make_float4(-inf, -inf, inf, inf) : make_float4(x0, y0, x1, y1);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------
 // Variant 0 = 50 (default): bounded groups over SPANS.  Same bounds, filter, bin decision and exact
 // fallback as sdf_tiles_hier<.., LAZY>; what changes is the unit of work of a workgroup: up to
 // SPAN = 4 consecutive 256-pixel tiles of ONE glyph.  A chunk of segments is staged (f64 loads,
@@ -1253,7 +1308,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
                                                       const double *__restrict__ seg_sy,
                                                       const double *__restrict__ seg_ex,
                                                       const double *__restrict__ seg_ey,
-                                                      uint8_t *__restrict__ out)
+                                                      uint8_t *__restrict__ out, const float4 *__restrict__ boxes)
 {
 	constexpr uint32_t GRP = 8, NGRP = FCHUNK / GRP; // 32 groups per chunk: one mask bit each
 	static_assert(NGRP == 32 && TPB == FCHUNK, "one candidate bit per group, one staging thread per record");
@@ -1292,9 +1347,28 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
 	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
 
+	// the box test pays for glyphs with several chunks; with one or two there is nothing to gain
+	const bool use_boxes = boxes != nullptr && !(ABL & 128) && g.n_seg > 2 * FCHUNK;
 	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
 		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
 		__syncthreads(); // previous chunk fully consumed (and s_delta / state initialised on the first trip)
+		if (use_boxes) {
+			// ---- chunk box test (workgroup-uniform).  Skip the chunk if its box lies strictly outside the
+			// span's band of sample rows (so none of its segments crosses one of them: no winding
+			// contribution) AND farther from every pixel of the span than R = min(max_p U_p, SAT): then each
+			// of its segments is beyond that pixel's true minimum, or beyond SAT where the byte is saturated
+			// whatever the minimum is.  f32 roundings (box, pixel centres, U) are covered by padk. ----
+			const float4 bb = boxes[chunk_box_index(g.seg_off, t.x, c0 / FCHUNK)];
+			const float mag = fmaxf(fmaxf(fabsf(bb.x), fabsf(bb.y)), fmaxf(fmaxf(fabsf(bb.z), fabsf(bb.w)), wh));
+			const float padk = 0.02f + 2.0e-6f * mag;
+			const float ry0 = (float)y_lo + 0.5f, ry1 = (float)y_hi + 0.5f; // sample rows of the span, relative to y0
+			const float dy = fmaxf(bb.y - ry1, ry0 - bb.w) - padk;
+			float dx = fmaxf(bb.x - ((float)g.w - 0.5f), 0.5f - bb.z) - padk;
+			dx = dx > 0.0f ? dx : 0.0f;
+			const float R = 6.2f + padk; // SAT
+			if (dy > 0.0f && __builtin_fmaf(dy, dy, dx * dx) > R * R)
+				continue; // NaN anywhere -> comparison false -> the chunk is processed
+		}
 		if (tid == 0)
 			s_mbits = __float_as_uint(wh);
 		__syncthreads();
@@ -1651,12 +1725,27 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 // ---------------------------------------------------------------------------------------
 extern "C" int vgsdf_filtered_delta_cap(void) { return vgsdf::DELTA_CAP; }
 
+extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs)
+{
+	return sizeof(float4) * (size_t)((n_segments >> 8) + n_glyphs + 2);
+}
+
+extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t n_glyphs, const double *sx, const double *sy,
+                                        const double *ex, const double *ey, void *boxes, hipStream_t stream)
+{
+	if (n_glyphs == 0)
+		return 0;
+	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3(n_glyphs), dim3(64), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
+	                   (float4 *)boxes);
+	return (int)hipGetLastError();
+}
+
 // variant ids: see vgsdf_batch_launch (vgsdf_device.cpp).  1 = brute force, also the fallback for the
 // tiles the host routes there: glyphs too wide for the winding histogram, or with >= 2^24 segments.
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
                                   const uint2 *tiles, uint32_t n_tiles_in, const double *sx,
                                   const double *sy, const double *ex, const double *ey, uint8_t *out,
-                                  hipStream_t stream)
+                                  const void *boxes, hipStream_t stream)
 {
 	if (n_tiles_in == 0)
 		return 0;
@@ -1671,7 +1760,7 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	                   sx, sy, ex, ey, out)
 #define VG_LAUNCH_SPAN(A)                                                                                 \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
-	                   sx, sy, ex, ey, out)
+	                   sx, sy, ex, ey, out, (const float4 *)boxes)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
@@ -1694,6 +1783,8 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_SPAN(1);
 	else if (variant == 56) // A/B: per-lane candidate walk instead of the pooled pairs
 		VG_LAUNCH_SPAN(64);
+	else if (variant == 57) // A/B: no chunk-box skipping
+		VG_LAUNCH_SPAN(128);
 	else if (variant == 45) // bounded groups, exact evaluation only where the byte is undecided
 		VG_LAUNCH_HIER(0, true);
 	else if (variant == 31) // timing-only: no phase 2

@@ -58,6 +58,7 @@ struct vgsdf_dbatch {
 	void *h_stage = nullptr; // pinned staging of the input part
 	vgsdf::GlyphDesc *d_glyphs = nullptr;
 	uint2 *d_tiles = nullptr;
+	void *d_boxes = nullptr; // chunk boxes (span kernel); NULL: none
 	double *d_sx = nullptr, *d_sy = nullptr, *d_ex = nullptr, *d_ey = nullptr;
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
@@ -99,7 +100,7 @@ struct DevBuf {
 
 struct FrontEnd {
 	DevBuf cmds, cmd_off, scale, shift, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
-	DevBuf sx, sy, ex, ey, descs_tiles, out;
+	DevBuf sx, sy, ex, ey, descs_tiles, out, boxes;
 	DevBuf h_rects, h_stage; // pinned
 	uint32_t n_glyphs = 0, n_cmds = 0, n_points = 0, n_segs = 0;
 	uint64_t out_bytes = 0;
@@ -114,7 +115,7 @@ struct FrontEnd {
 	void release_all()
 	{
 		for (DevBuf *b : {&cmds, &cmd_off, &scale, &shift, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
-		                  &seg_count, &seg_off, &scan_tmp, &sx, &sy, &ex, &ey, &descs_tiles, &out, &h_rects, &h_stage})
+		                  &seg_count, &seg_off, &scan_tmp, &sx, &sy, &ex, &ey, &descs_tiles, &out, &boxes, &h_rects, &h_stage})
 			b->release();
 	}
 };
@@ -436,6 +437,8 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	b->input_bytes = off;
 	const size_t off_out = off;
 	off = align_up(off + (size_t)n_pix, A);
+	const size_t off_boxes = off;
+	off = align_up(off + vgsdf_chunk_box_bytes(n_seg, n), A);
 	b->arena_bytes = off ? off : A;
 
 	(void)hipSetDevice(ctx->device);
@@ -500,6 +503,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	b->d_ex = (double *)(da + off_ex);
 	b->d_ey = (double *)(da + off_ey);
 	b->d_out = da + off_out;
+	b->d_boxes = da + off_boxes;
 
 	if (n) {
 		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
@@ -522,6 +526,8 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			if (e == hipSuccess)
 				e = hipMemcpyAsync(b->d_ey, in->seg_ey, nb, hipMemcpyHostToDevice, ctx->stream);
 		}
+		if (e == hipSuccess && b->span_list)
+			e = (hipError_t)vgsdf_launch_chunk_boxes(b->d_glyphs, n, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_boxes, ctx->stream);
 		if (e != hipSuccess) {
 			ctx->err = std::string("vgsdf_batch_upload: H2D: ") + hipGetErrorString(e);
 			vgsdf_batch_free(ctx, b);
@@ -578,10 +584,10 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	}
 	const int list_order = b->tile_order == 1;
 	int e = vgsdf_launch_tiles(k_main, list_order, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
-	                           b->d_out, ctx->stream);
+	                           b->d_out, b->span_list ? b->d_boxes : nullptr, ctx->stream);
 	if (e == 0)
 		e = vgsdf_launch_tiles(1, list_order, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
-		                       b->d_ey, b->d_out, ctx->stream);
+		                       b->d_ey, b->d_out, nullptr, ctx->stream);
 	if (e != 0) {
 		ctx->err = std::string("vgsdf_batch_launch: ") + hipGetErrorString((hipError_t)e);
 		return VGSDF_E_HIP;
@@ -856,6 +862,12 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	b.d_ex = (double *)fe.ex.p;
 	b.d_ey = (double *)fe.ey.p;
 	b.d_out = (uint8_t *)fe.out.p;
+	b.d_boxes = nullptr;
+	if (b.span_list) {
+		FE_TRY(fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.n_segs, n) + 16));
+		b.d_boxes = fe.boxes.p;
+		FE_TRY((hipError_t)vgsdf_launch_chunk_boxes(b.d_glyphs, n, b.d_sx, b.d_sy, b.d_ex, b.d_ey, b.d_boxes, st));
+	}
 	fe.prepared = true;
 	if (out_bytes)
 		*out_bytes = fe.out_bytes;
