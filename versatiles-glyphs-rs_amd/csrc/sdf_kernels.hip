@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 						D2p[b * 2] = __builtin_amdgcn_perm(d2[1], d2[0], 0x07060302u);     // hi16(d2[1]) : hi16(d2[0])
 						D2p[b * 2 + 1] = __builtin_amdgcn_perm(d2[3], d2[2], 0x07060302u);
 					} else {
-						D2p[b * 2] = D2p[b * 2 + 1] = 0x7F807F80u; // +inf : +inf
+						D2p[b * 2] = D2p[b * 2 + 1] = 0x7F7F7F7Fu; // 3.4e38 : 3.4e38 (finite: the test below stays NaN-free)
 					}
 				}
 				ub2 = __uint_as_float(dmin);
@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
 				const float Ui = U * 1.004f; // s_gr is stored with the same factor
 				// One bit per group, 3-4 VALU ops each: tt = (U + r_g) 1.004, diff = tt^2 - D_g^2 (sign bit set
-				// <=> not a candidate; -inf for the groups past n_groups), shifted in with v_alignbit.  The
+				// <=> not a candidate; -3.4e38 for the groups past n_groups), shifted in with v_alignbit.  The
 				// bits arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
 				uint32_t rej = 0xFFFFFFFFu;
 #pragma unroll
@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 						rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(diff), 31); // (rej << 1) | sign(diff)
 					}
 				}
-				cand = __builtin_bitreverse32(~rej);
+				cand &= __builtin_bitreverse32(~rej); // (cand starts as the mask of the chunk's real groups)
 			}
 
 
