@@ -1335,6 +1335,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	const uint32_t r_first = p0 / g.w, r_last = (p_end - 1) / g.w;
 	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
 	const uint32_t stride = g.w + 1;
+	const double band_lo = (double)y_lo + y0c, band_hi = (double)y_hi + y0c; // lowest / highest sample row of the span
 	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
 	for (uint32_t i = tid; i < n_delta; i += TPB)
 		s_delta[i] = 0;
@@ -1403,13 +1404,18 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				mf = (float)m * 1.000001f;               // round up
 				mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
 				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
-				if (!(ABL & 1) && vy != wy) {
-					const bool up = vy < wy;
-					const double lo = up ? vy : wy, hi = up ? wy : vy;
+				// Rows crossed: lo <= py < hi with py = yy + y0c exactly as the reference forms it.  Most
+				// segments of a real font are a fraction of a pixel tall and most lie outside the span's band
+				// of rows: two exact compares reject those before the integer bracket is computed, and the
+				// upper end of the range is found by walking (py < hi) instead of a second bracket.
+				const bool up = vy < wy;
+				const double lo = up ? vy : wy, hi = up ? wy : vy;
+				if (!(ABL & 1) && vy != wy && hi > band_lo && lo <= band_hi) {
 					const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
-					const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
-					for (int yy = ya; yy < yb; yy++) {
+					for (int yy = ya; yy <= y_hi; yy++) {
 						const double pyy = (double)yy + y0c;
+						if (!(pyy < hi))
+							break;
 						const double tc = (pyy - vy) / dy;
 						const double xc = vx + tc * dx;               // :45-46 / :48-49
 						const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
