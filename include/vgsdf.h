@@ -108,8 +108,10 @@ int vgsdf_batch_stats(const vgsdf_dbatch *b, vgsdf_stats *out);
  * context stream (the stream the kernel runs on); *total_ms = elapsed for all of them. */
 int vgsdf_batch_time(vgsdf_ctx *ctx, vgsdf_dbatch *b, int iters, float *total_ms);
 
-/* Selects the kernel variant: 0 = default (best verified), other values select
- * alternative implementations for A/B measurements. */
+/* Selects the kernel variant: 0 = default (best verified); 1 = brute force; other values select the
+ * earlier kernel generations kept for A/B measurements (all bit-exact).  Set it
+ * BEFORE uploading / preparing a batch: the work list layout depends on it, and launching a
+ * resident batch under a different variant fails with VGSDF_E_ARG. */
 int vgsdf_set_variant(vgsdf_ctx *ctx, int variant);
 
 /*

@@ -62,9 +62,8 @@ struct vgsdf_dbatch {
 	double *d_sx = nullptr, *d_sy = nullptr, *d_ex = nullptr, *d_ey = nullptr;
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
-	// tile list = [filtered | filtered+culling | brute force]
-	uint32_t n_main = 0; // tiles [0, n_main): filtered kernel (both flavours)
-	uint32_t n_plain = 0; // tiles [0, n_plain): filtered without culling (small glyphs)
+	// work list = [main kernel | brute force]
+	uint32_t n_main = 0; // entries [0, n_main): main kernel; the rest: brute-force tiles
 	int tile_order = 1;
 	bool span_list = false; // main-class entries are (glyph, first pixel | tile count): sdf_tiles_span only
 	bool borrowed = false; // arena + staging belong to the context (vgsdf_render_batch)
@@ -350,8 +349,6 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 			for (uint32_t g : gl)
 				emit(g, [&](uint2 e) { ht[ti++] = e; });
 		}
-		if (cls == 0)
-			b->n_plain = (uint32_t)ti;
 		if (cls == 1)
 			b->n_main = (uint32_t)ti;
 	}
