@@ -1,0 +1,97 @@
+"""Differential fuzzing of the device front-end (outline commands -> flattened, closed, scaled
+segments + rects) against the oracle's RingBuilder restatement: random command streams, including
+ones ttf-parser never emits (curves on an empty ring, missing / repeated closes, cubic segments,
+degenerate and repeated points, tiny and huge coordinates).  Exits non-zero at the first difference."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from conftest import load_product  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+vg = load_product()
+budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = vg.SdfContext(0)
+M, L, Q, C, Z = 0, 1, 2, 3, 4
+
+
+def f32(v):
+    return float(np.float32(v))
+
+
+def stream():
+    n = int(rng.choice([0, 1, 3, 8, 30, 120]))
+    span = float(rng.choice([50, 1000, 2048, 16000]))
+    snap = rng.choice([0, 0, 1, 4])
+    cmds = []
+    def pt():
+        p = rng.uniform(-0.1 * span, span, 2)
+        if snap:
+            p = np.round(p / snap) * snap
+        return f32(p[0]), f32(p[1])
+    last = pt()
+    for _ in range(n):
+        k = rng.choice([M, L, L, L, Q, Q, Q, C, Z], p=[.08, .12, .12, .12, .14, .14, .14, .08, .06])
+        if k == M or k == L:
+            x, y = pt() if rng.random() > 0.1 else last
+            cmds.append((int(k), 0, 0, 0, 0, x, y)); last = (x, y)
+        elif k == Q:
+            (x1, y1), (x, y) = pt(), pt()
+            if rng.random() < 0.1:
+                x1, y1 = last  # degenerate control point
+            cmds.append((Q, x1, y1, 0, 0, x, y)); last = (x, y)
+        elif k == C:
+            (x1, y1), (x2, y2), (x, y) = pt(), pt(), pt()
+            cmds.append((C, x1, y1, x2, y2, x, y)); last = (x, y)
+        else:
+            cmds.append((Z, 0, 0, 0, 0, 0, 0))
+    return cmds, 24.0 / float(rng.choice([1000, 2048, 256, 16384])), float(rng.uniform(-0.5, 0.5))
+
+
+t0 = time.time()
+n_batches = n_streams = n_segs = 0
+while time.time() - t0 < budget_s:
+    sts = [stream() for _ in range(int(rng.integers(1, 60)))]
+    cmds, cmd_off = [], [0]
+    for st, _, _ in sts:
+        cmds += [(c[1], c[2], c[3], c[4], c[5], c[6], c[0]) for c in st]
+        cmd_off.append(len(cmds))
+    scale = np.array([s for _, s, _ in sts]); shift = np.array([d for _, _, d in sts])
+    rects, _, _ = ctx.outlines_prepare(np.array(cmd_off, np.uint32), np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE).reshape(-1), scale, shift)
+    seg_off, segs = ctx.outlines_segments()
+    for g, (st, sc, dx) in enumerate(sts):
+        want = []
+        for r in O.build_rings(st):
+            p = r * sc
+            p[:, 0] += dx
+            p[:, 1] += 0.0
+            want.append(np.concatenate([p[:-1], p[1:]], axis=1))
+        want = np.concatenate(want) if want else np.zeros((0, 4))
+        got = segs[seg_off[g]:seg_off[g + 1]]
+        ok = got.tobytes() == want.tobytes() if len(want) else True
+        if len(want):
+            allp = np.concatenate([want[:, :2], want[:, 2:]])
+            empty = allp[:, 0].max() <= allp[:, 0].min() and allp[:, 1].max() <= allp[:, 1].min()  # bbox.rs:56-58
+            if empty:
+                ok = int(rects[g]["has_raster"]) == 0
+            else:
+                ok = ok and int(rects[g]["has_raster"]) == 1 and int(rects[g]["x0"]) == int(np.floor(allp[:, 0].min())) - 3 \
+                    and int(rects[g]["y0"]) == int(np.floor(allp[:, 1].min())) - 3 \
+                    and int(rects[g]["w"]) == int(np.ceil(allp[:, 0].max())) + 3 - (int(np.floor(allp[:, 0].min())) - 3) \
+                    and int(rects[g]["h"]) == int(np.ceil(allp[:, 1].max())) + 3 - (int(np.floor(allp[:, 1].min())) - 3)
+        else:
+            ok = int(rects[g]["has_raster"]) == 0 and len(got) == 0
+        if not ok:
+            print(f"MISMATCH seed {seed} batch {n_batches} stream {g}: {len(got)} vs {len(want)} segments, rect {rects[g]}\n{st}", flush=True)
+            sys.exit(1)
+        n_segs += len(want)
+    n_batches += 1; n_streams += len(sts)
+    if n_batches % 50 == 0:
+        print(f"[{time.time() - t0:6.0f} s] {n_batches} batches, {n_streams} streams, {n_segs / 1e6:.2f} M segments: all equal", flush=True)
+print(f"done: {n_batches} batches, {n_streams} command streams, {n_segs / 1e6:.2f} M segments, 0 differences (seed {seed})", flush=True)
