@@ -112,10 +112,25 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        from datetime import timedelta
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=timedelta(seconds=300))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)          # the collectives below carry 32 bytes in total:
+                torch.cuda.synchronize()        # make sure RCCL works before anything is timed
+            except Exception as e:              # noqa: BLE001  (a number over gloo beats no number)
+                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); counters and barriers go over gloo",
+                      file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:               # noqa: BLE001
+                    pass
+                backend, coll_dev = "gloo", "cpu"
+                dist.init_process_group(backend="gloo", timeout=timedelta(seconds=300))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=timedelta(seconds=300))
 
     vg = load_product()
     if vg.device_count() <= local_rank:
@@ -204,6 +219,7 @@ def main():
             "tiles": st["n_tiles"],
             "kernel_variant": args.variant,
             "parallelism": f"replica x{world} (glyph batches shard with no exchange)",
+            "collectives": ("none" if world == 1 else f"{backend}: barrier, max(time), sum of 3 counters"),
         },
         "mpixel_sdf_per_s": counters[2] * steps / elapsed * 1e-6,
         "roofline": {
