@@ -98,7 +98,7 @@ struct DevBuf {
 };
 
 struct FrontEnd {
-	DevBuf cmds, cmd_off, scale, shift, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
+	DevBuf cmds, meta, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
 	DevBuf sx, sy, ex, ey, descs_tiles, out, boxes;
 	DevBuf h_rects, h_stage; // pinned
 	uint32_t n_glyphs = 0, n_cmds = 0, n_points = 0, n_segs = 0;
@@ -113,7 +113,7 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &cmd_off, &scale, &shift, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
+		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
 		                  &seg_count, &seg_off, &scan_tmp, &sx, &sy, &ex, &ey, &descs_tiles, &out, &boxes, &h_rects, &h_stage})
 			b->release();
 	}
@@ -737,9 +737,10 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	tr1 = fe_now();
 	hipStream_t st = ctx->stream;
 	FE_TRY(fe.cmds.ensure(sizeof(vgsdf::OutlineCmd) * (size_t)(n_cmds + 1)));
-	FE_TRY(fe.cmd_off.ensure(4 * (size_t)(n + 1)));
-	FE_TRY(fe.scale.ensure(8 * (size_t)n));
-	FE_TRY(fe.shift.ensure(8 * (size_t)n));
+	// per-glyph inputs (scale, shift, command offsets) travel as ONE block through pinned staging
+	const size_t meta_scale = 0, meta_shift = 8 * (size_t)n, meta_off = 16 * (size_t)n, meta_bytes = meta_off + 4 * (size_t)(n + 1);
+	FE_TRY(fe.meta.ensure(meta_bytes + 16));
+	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
 	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.pt_off.ensure(4 * (size_t)(n_cmds + 1)));
@@ -754,12 +755,19 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 
 	if (n_cmds)
 		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
-	FE_TRY(hipMemcpyAsync(fe.cmd_off.p, in->cmd_off, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
-	FE_TRY(hipMemcpyAsync(fe.scale.p, in->scale, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-	FE_TRY(hipMemcpyAsync(fe.shift.p, in->shift_x, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+	{
+		uint8_t *hm = (uint8_t *)fe.h_stage.p;
+		std::memcpy(hm + meta_scale, in->scale, 8 * (size_t)n);
+		std::memcpy(hm + meta_shift, in->shift_x, 8 * (size_t)n);
+		std::memcpy(hm + meta_off, in->cmd_off, 4 * (size_t)(n + 1));
+		FE_TRY(hipMemcpyAsync(fe.meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
+	}
+	const double *d_scale = (const double *)((const uint8_t *)fe.meta.p + meta_scale);
+	const double *d_shift = (const double *)((const uint8_t *)fe.meta.p + meta_shift);
+	const uint32_t *d_cmd_off = (const uint32_t *)((const uint8_t *)fe.meta.p + meta_off);
 
 	auto *d_cmds = (const vgsdf::OutlineCmd *)fe.cmds.p;
-	FE_KERNEL(vgsdf_outline_context(d_cmds, (const uint32_t *)fe.cmd_off.p, n, (uint8_t *)fe.cmd_open.p, st));
+	FE_KERNEL(vgsdf_outline_context(d_cmds, d_cmd_off, n, (uint8_t *)fe.cmd_open.p, st));
 	FE_KERNEL(vgsdf_outline_count(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (uint32_t *)fe.counts.p, st));
 	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_off.p,
 	                             n_cmds + 1, st));
@@ -784,8 +792,8 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 
 	FE_KERNEL(vgsdf_outline_emit(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (const uint32_t *)fe.pt_off.p,
 	                             (double *)fe.ptx.p, (double *)fe.pty.p, st));
-	FE_KERNEL(vgsdf_outline_rings(d_cmds, (const uint32_t *)fe.cmd_off.p, (const uint32_t *)fe.pt_off.p, (const double *)fe.ptx.p,
-	                              (const double *)fe.pty.p, (const double *)fe.scale.p, (const double *)fe.shift.p, n,
+	FE_KERNEL(vgsdf_outline_rings(d_cmds, d_cmd_off, (const uint32_t *)fe.pt_off.p, (const double *)fe.ptx.p,
+	                              (const double *)fe.pty.p, d_scale, d_shift, n,
 	                              (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, (vgsdf::OutlineRect *)fe.rects.p,
 	                              (uint32_t *)fe.seg_count.p, st));
 	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.seg_count.p, (uint32_t *)fe.seg_off.p,
@@ -793,7 +801,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_KERNEL(vgsdf_outline_segments((const uint32_t *)fe.pt_off.p, n_cmds, n_points, (const uint32_t *)fe.cmd_ring.p,
 	                                 (const vgsdf::RingRec *)fe.rings.p, (const vgsdf::OutlineRect *)fe.rects.p,
 	                                 (const uint32_t *)fe.seg_off.p, (const double *)fe.ptx.p, (const double *)fe.pty.p,
-	                                 (const double *)fe.scale.p, (const double *)fe.shift.p, (double *)fe.sx.p, (double *)fe.sy.p,
+	                                 d_scale, d_shift, (double *)fe.sx.p, (double *)fe.sy.p,
 	                                 (double *)fe.ex.p, (double *)fe.ey.p, st));
 	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects.p, sizeof(vgsdf::OutlineRect) * (size_t)n, hipMemcpyDeviceToHost, st));
 	FE_TRY(hipStreamSynchronize(st));
@@ -801,9 +809,15 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	tr3 = fe_now();
 
 	// host: offsets, descriptors, tile list (same routing/order as the segment entry points)
-	std::vector<uint32_t> seg_off(n + 1, 0), w(n), h(n);
-	std::vector<int32_t> x0(n), y0(n);
-	std::vector<uint64_t> out_off(n + 1, 0);
+	static thread_local std::vector<uint32_t> seg_off, w, h;
+	static thread_local std::vector<int32_t> x0, y0;
+	static thread_local std::vector<uint64_t> out_off;
+	seg_off.assign(n + 1, 0);
+	out_off.assign(n + 1, 0);
+	w.resize(n);
+	h.resize(n);
+	x0.resize(n);
+	y0.resize(n);
 	uint64_t n_tiles = 0, n_pairs = 0;
 	for (uint32_t g = 0; g < n; g++) {
 		const vgsdf_rect &r = rects_out[g];
