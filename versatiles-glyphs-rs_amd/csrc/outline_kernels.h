@@ -45,11 +45,11 @@ int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off
 int vgsdf_outline_count(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, uint32_t *counts,
                         hipStream_t stream);
 int vgsdf_outline_emit(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *pt_off,
-                       double *ptx, double *pty, hipStream_t stream);
+                       double *ptx, double *pty, void *cmd_box /* double4 per command */, hipStream_t stream);
 int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const uint32_t *pt_off, const double *ptx,
                         const double *pty, const double *scale, const double *shift_x, uint32_t n_glyphs,
                         vgsdf::RingRec *rings, uint32_t *cmd_ring, vgsdf::OutlineRect *rects, uint32_t *seg_count,
-                        hipStream_t stream);
+                        const void *cmd_box, hipStream_t stream);
 int vgsdf_outline_segments(const uint32_t *pt_off, uint32_t n_cmds, uint32_t n_points, const uint32_t *cmd_ring,
                            const vgsdf::RingRec *rings, const vgsdf::OutlineRect *rects, const uint32_t *seg_off,
                            const double *ptx, const double *pty, const double *scale, const double *shift_x, double *sx,

@@ -1251,11 +1251,14 @@ __global__ __launch_bounds__(64) void sdf_chunk_boxes(const GlyphDesc *__restric
                                                       const double *__restrict__ seg_ex,
                                                       const double *__restrict__ seg_ey, float4 *__restrict__ boxes)
 {
+	// grid = (glyphs, CHUNK_BOX_Y): chunk c of a glyph is taken by the wave with blockIdx.y == c % gridDim.y, so
+	// the 18 chunks of a long glyph are not walked one after the other by a single wave
 	const uint32_t gi = blockIdx.x, lane = threadIdx.x;
 	if (gi >= n_glyphs)
 		return;
 	const GlyphDesc g = glyphs[gi];
-	for (uint32_t c0 = 0, c = 0; c0 < g.n_seg; c0 += FCHUNK, c++) {
+	for (uint32_t c = blockIdx.y; (uint64_t)c * FCHUNK < g.n_seg; c += gridDim.y) {
+		const uint32_t c0 = c * FCHUNK;
 		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
 		float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
 		bool bad = false;
@@ -1741,7 +1744,7 @@ extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t
 {
 	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3(n_glyphs), dim3(64), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
+	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3(n_glyphs, 4), dim3(64), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
 	                   (float4 *)boxes);
 	return (int)hipGetLastError();
 }

@@ -98,7 +98,7 @@ struct DevBuf {
 };
 
 struct FrontEnd {
-	DevBuf cmds, meta, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
+	DevBuf cmds, meta, cmd_box, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
 	DevBuf sx, sy, ex, ey, descs_tiles, out, boxes;
 	DevBuf h_rects, h_stage; // pinned
 	uint32_t n_glyphs = 0, n_cmds = 0, n_points = 0, n_segs = 0;
@@ -113,7 +113,7 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
+		for (DevBuf *b : {&cmds, &meta, &cmd_box, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
 		                  &seg_count, &seg_off, &scan_tmp, &sx, &sy, &ex, &ey, &descs_tiles, &out, &boxes, &h_rects, &h_stage})
 			b->release();
 	}
@@ -742,6 +742,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(fe.meta.ensure(meta_bytes + 16));
 	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
+	FE_TRY(fe.cmd_box.ensure(32 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.pt_off.ensure(4 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.rings.ensure(sizeof(vgsdf::RingRec) * (size_t)(n_cmds + 1)));
@@ -791,11 +792,11 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(fe.ey.ensure(8 * (size_t)n_points + 8));
 
 	FE_KERNEL(vgsdf_outline_emit(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (const uint32_t *)fe.pt_off.p,
-	                             (double *)fe.ptx.p, (double *)fe.pty.p, st));
+	                             (double *)fe.ptx.p, (double *)fe.pty.p, fe.cmd_box.p, st));
 	FE_KERNEL(vgsdf_outline_rings(d_cmds, d_cmd_off, (const uint32_t *)fe.pt_off.p, (const double *)fe.ptx.p,
 	                              (const double *)fe.pty.p, d_scale, d_shift, n,
 	                              (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, (vgsdf::OutlineRect *)fe.rects.p,
-	                              (uint32_t *)fe.seg_count.p, st));
+	                              (uint32_t *)fe.seg_count.p, fe.cmd_box.p, st));
 	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.seg_count.p, (uint32_t *)fe.seg_off.p,
 	                             n + 1, st));
 	FE_KERNEL(vgsdf_outline_segments((const uint32_t *)fe.pt_off.p, n_cmds, n_points, (const uint32_t *)fe.cmd_ring.p,
