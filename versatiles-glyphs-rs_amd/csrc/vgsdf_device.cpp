@@ -360,25 +360,33 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 			// with its own L2).  Keep all tiles of a glyph on ONE XCD so its segment list is fetched
 			// into one L2 only: glyphs are dealt to the currently shortest of 8 per-XCD queues, and
 			// the queues are interleaved position by position.
-			for (int q = 0; q < 8; q++)
-				queue[q].clear();
+			size_t qlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			uint2 *qbuf[8];
+			for (int q = 0; q < 8; q++) {
+				if (queue[q].size() < n_cls_tiles)
+					queue[q].resize(n_cls_tiles); // plain arrays below: no capacity checks per entry
+				qbuf[q] = queue[q].data();
+			}
 			for (uint64_t k : gl) {
 				size_t best = 0;
 				for (size_t m = 1; m < 8; m++)
-					if (queue[m].size() < queue[best].size())
+					if (qlen[m] < qlen[best])
 						best = m;
-				emit((uint32_t)k, [&](uint2 e) { queue[best].push_back(e); });
+				uint2 *dst = qbuf[best];
+				size_t len = qlen[best];
+				emit((uint32_t)k, [&](uint2 e) { dst[len++] = e; });
+				qlen[best] = len;
 			}
 			size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 			const uint64_t last = first + n_cls_tiles;
 			while (ti < last)
 				for (size_t k = 0; k < 8 && ti < last; k++) {
 					size_t src = k; // position ti runs on XCD ti % 8 == k as long as no queue ran dry
-					if (taken[src] >= queue[src].size())
+					if (taken[src] >= qlen[src])
 						for (size_t m = 0; m < 8; m++) // dry: borrow from the fullest queue
-							if (queue[m].size() - taken[m] > queue[src].size() - taken[src])
+							if (qlen[m] - taken[m] > qlen[src] - taken[src])
 								src = m;
-					ht[ti++] = queue[src][taken[src]++];
+					ht[ti++] = qbuf[src][taken[src]++];
 				}
 		} else {
 			for (uint64_t k : gl)
