@@ -1359,9 +1359,10 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 		if (use_boxes) {
 			// ---- chunk box test (workgroup-uniform).  Skip the chunk if its box lies strictly outside the
 			// span's band of sample rows (so none of its segments crosses one of them: no winding
-			// contribution) AND farther from every pixel of the span than R = min(max_p U_p, SAT): then each
-			// of its segments is beyond that pixel's true minimum, or beyond SAT where the byte is saturated
-			// whatever the minimum is.  f32 roundings (box, pixel centres, U) are covered by padk. ----
+			// contribution) AND farther than SAT from every pixel of the span: a segment beyond SAT is either
+			// not the minimum, or the byte is saturated whatever the minimum is.  f32 roundings (box, pixel
+			// centres) are covered by padk.  (Tightening R with the pixels' running upper bounds was
+			// measured: the bookkeeping costs more than the extra skips on real fonts.) ----
 			const float4 bb = boxes[chunk_box_index(g.seg_off, t.x, c0 / FCHUNK)];
 			const float mag = fmaxf(fmaxf(fabsf(bb.x), fabsf(bb.y)), fmaxf(fmaxf(fabsf(bb.z), fabsf(bb.w)), wh));
 			const float padk = 0.02f + 2.0e-6f * mag;
