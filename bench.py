@@ -308,6 +308,21 @@ def main():
                                  "seconds_with_python_writer": best_py, "pbf_files": n_files, "pbf_bytes": n_bytes,
                                  "phases_s": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
         out["e2e"]["gpu_path_glyphs_per_s"] = out["e2e"]["device_front_end"]["glyphs_per_s"]
+        # many small fonts in one manager (every fixture file as its own font): submissions are grouped
+        many = vg.FontManager(True)
+        td = ROOT / "testdata"
+        for i, p in enumerate([td / "Fira Sans - Regular.ttf"] + sorted((td / "Noto Sans").glob("*.ttf"), key=lambda q: q.name)):
+            many.add_font_with_name(f"Font {i:02d}", [p])
+        many.render_glyphs(None, r)
+        best = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            many.render_glyphs(None, r)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        tm = many.timings()
+        out["e2e"]["all_21_fixture_fonts_as_separate_fonts"] = {"glyphs_per_s": tm["glyphs"] / best, "seconds": best,
+                                                                 "glyphs": tm["glyphs"], "pbf_bytes": tm["pbf_bytes"]}
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             fonts = [O.Font(p) for p in paths]

@@ -75,3 +75,28 @@ def test_single_threaded_and_batched_agree(vg, hip):
     b = render_all_files(vg, hip, "Fira Sans Regular", [FIRA], threads=4, blocks_per_batch=256)[1].files
     c = render_all_files(vg, hip, "Fira Sans Regular", [FIRA], threads=3, blocks_per_batch=5, device_front_end=False)[1].files
     assert a == b == c
+
+
+def test_several_fonts_in_groups(vg, hip):
+    """several fonts in one manager go through the device front-end group by group (reused buffers).
+    Every file must equal what the same font gives when it is rendered alone, and arrive in task order
+    (fonts sorted by id, blocks ascending) — also with groups smaller than a font and with the null sink."""
+    fonts = [("Fira Sans Regular", [FIRA]), ("Noto Sans Regular", [NOTO])] + \
+            [(f"Noto {i}", [p]) for i, p in enumerate(noto_files()[:5])]
+    alone = {}
+    for name, paths in fonts:
+        fid, w, _ = render_all_files(vg, hip, name, paths)
+        alone.update(w.files)
+    for blocks_per_batch in (0, 100, 7):
+        m = vg.FontManager(True)
+        m.set_threads(0, blocks_per_batch)
+        for name, paths in fonts:
+            m.add_font_with_name(name, paths)
+        w = vg.DummyWriter()
+        m.render_glyphs(w, hip)
+        assert set(w.files) == set(alone)
+        assert all(w.files[k] == alone[k] for k in alone), blocks_per_batch
+        order = [s.split(" (")[0] for s in w.inner if s.endswith(")")]
+        assert order == sorted(order, key=lambda p: (p.split("/")[0], int(p.split("/")[1].split("-")[0])))
+        m.render_glyphs(None, hip)
+        assert m.timings()["pbf_bytes"] == sum(len(v) for v in alone.values())

@@ -7,14 +7,20 @@ from conftest import load_product, NOTO, noto_files
 vg = load_product()
 which = sys.argv[1] if len(sys.argv) > 1 else "noto_regular"
 paths = [NOTO] if which == "noto_regular" else noto_files()
+many = which == "many"  # every fixture file as its own font: 21 groups through the pipelined dispatcher
 r = vg.Renderer.new_precise(0) if vg.device_count() else vg.Renderer.new_dummy()
 fe = len(sys.argv) > 2 and sys.argv[2] == "fe"
 for th in (4, 16):
-    m = vg.FontManager(True); m.set_threads(th, 256 if fe else 0); m.set_device_front_end(fe)
-    fid = m.add_font_with_name("Noto Sans Regular", paths)
+    m = vg.FontManager(True); m.set_threads(th, int(sys.argv[3]) if len(sys.argv) > 3 else 0); m.set_device_front_end(fe)
+    if many:
+        from conftest import FIRA
+        for i, p in enumerate([FIRA] + list(noto_files())):
+            m.add_font_with_name(f"Font {i:02d}", [p])
+    else:
+        fid = m.add_font_with_name("Noto Sans Regular", paths)
     best = None
     for i in range(4):
-        w = vg.DummyWriter(); t = time.perf_counter(); m.render_glyphs(w, r); dt = time.perf_counter() - t
+        w = None if many else vg.DummyWriter(); t = time.perf_counter(); m.render_glyphs(w, r); dt = time.perf_counter() - t
         if i == 0: cold = dt
         best = dt if best is None else min(best, dt)
     tm = m.timings()

@@ -333,137 +333,169 @@ void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const 
 // The same dispatcher with the DEVICE front-end: host threads only look glyphs up and record
 // their outline commands; flattening, ring rules, scale/shift, bbox and the raster run on the
 // GPU (one prepare + one render submission per group of blocks).
-void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer)
+// Host half of the device front-end for tasks [G.g0, G.g1): look the glyphs up, record their outline
+// commands on the pool (64-code-point slices, worker-local buffers), merge in task order into the
+// group's page-locked arrays.
+void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 {
 	constexpr uint32_t kSlice = 64;
+	ThreadPool &tp = pool();
+	const double t0 = now_s();
+	std::vector<OSlice> &slices = G.slices;
+	slices.clear();
+	G.slice_ci.clear();
+	for (size_t t = G.g0; t < G.g1; t++) {
+		if (tasks[t].block.is_empty())
+			continue;
+		for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += kSlice) {
+			OSlice s;
+			s.task = (uint32_t)t;
+			slices.push_back(s);
+			G.slice_ci.push_back(c);
+		}
+	}
+	for (Worker &w : workers_)
+		w.olocal.clear();
+	tp.run(slices.size(), [&](size_t i, unsigned wid) {
+		OSlice &s = slices[i];
+		Worker &w = workers_[wid];
+		s.worker = wid;
+		s.job0 = (uint32_t)w.olocal.jobs.size();
+		const GlyphBlock &blk = tasks[s.task].block;
+		for (uint32_t ci = G.slice_ci[i]; ci < G.slice_ci[i] + kSlice; ci++)
+			if (const FontFileEntry *f = blk.glyphs[ci])
+				Renderer::record(f->face(), blk.start_index + ci, w.olocal);
+		s.job1 = (uint32_t)w.olocal.jobs.size();
+	});
+	const double t1 = now_s();
+	timings_.tessellate_s += t1 - t0;
+
+	// merge in task order
+	uint32_t n_jobs = 0, n_cmds = 0;
+	G.slice_cmd.resize(slices.size());
+	for (size_t i = 0; i < slices.size(); i++) {
+		OSlice &s = slices[i];
+		const OutlineBatch &l = workers_[s.worker].olocal;
+		s.g_job = n_jobs;
+		G.slice_cmd[i] = n_cmds;
+		n_jobs += s.job1 - s.job0;
+		n_cmds += l.cmd_off[s.job1] - l.cmd_off[s.job0];
+	}
+	G.n_jobs = n_jobs;
+	MergedOutlines &m = G.m;
+	m.jobs.resize(n_jobs);
+	m.cmd_off.resize((size_t)n_jobs + 1);
+	m.cmds.ensure((size_t)n_cmds + 1);
+	m.scale.resize(n_jobs);
+	m.shift_x.resize(n_jobs);
+	m.cmd_off[0] = 0;
+	tp.run(slices.size(), [&](size_t i, unsigned) {
+		const OSlice &s = slices[i];
+		const OutlineBatch &l = workers_[s.worker].olocal;
+		const uint32_t lc0 = l.cmd_off[s.job0];
+		const size_t nc = l.cmd_off[s.job1] - lc0;
+		if (nc)
+			std::memcpy(m.cmds.data() + G.slice_cmd[i], l.cmds.data() + lc0, nc * sizeof(vgsdf_outline_cmd));
+		for (uint32_t j = s.job0; j < s.job1; j++) {
+			const uint32_t g = s.g_job + (j - s.job0);
+			m.jobs[g] = l.jobs[j];
+			m.scale[g] = l.scale[j];
+			m.shift_x[g] = l.shift_x[j];
+			m.cmd_off[g + 1] = G.slice_cmd[i] + (l.cmd_off[j + 1] - lc0);
+		}
+	});
+	timings_.pack_s += now_s() - t1;
+}
+
+// Rects + bitmaps of a rendered group -> PbfGlyphs per block (pool), written in task order.
+void FontManager::fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer)
+{
+	ThreadPool &tp = pool();
+	const double t3 = now_s();
+	const size_t nb = G.g1 - G.g0;
+	const uint32_t n_jobs = G.n_jobs;
+	MergedOutlines &m = G.m;
+	// bitmap offsets: rasterised glyphs are packed in job order
+	std::vector<uint64_t> boff((size_t)n_jobs + 1, 0);
+	uint64_t n_raster = 0;
+	for (uint32_t g = 0; g < n_jobs; g++) {
+		const vgsdf_rect &r = G.rects[g];
+		GlyphJob &job = m.jobs[g];
+		job.has_raster = r.has_raster != 0;
+		job.x0 = r.x0;
+		job.y0 = r.y0;
+		job.width = r.w;
+		job.height = r.h;
+		job.x1 = r.x0 + (int32_t)r.w;
+		job.y1 = r.y0 + (int32_t)r.h;
+		job.n_segments = r.n_segments;
+		boff[g + 1] = boff[g] + (job.has_raster ? (uint64_t)r.w * r.h : 0);
+		n_raster += job.has_raster;
+	}
+	std::vector<std::pair<size_t, size_t>> span(nb, {0, 0});
+	for (size_t i = 0; i < G.slices.size(); i++) {
+		auto &sp = span[G.slices[i].task - G.g0];
+		if (sp.second == 0)
+			sp.first = i;
+		sp.second = i + 1;
+	}
+	std::vector<std::vector<uint8_t>> encoded(nb);
+	tp.run(nb, [&](size_t i, unsigned) {
+		std::vector<PbfGlyphRef> refs;
+		for (size_t k = span[i].first; k < span[i].second; k++) {
+			const OSlice &s = G.slices[k];
+			for (uint32_t j = 0; j < s.job1 - s.job0; j++) {
+				const uint32_t g = s.g_job + j;
+				const GlyphJob &job = m.jobs[g];
+				refs.push_back(job.to_pbf(job.has_raster ? G.out.data() + boff[g] : nullptr));
+			}
+		}
+		encoded[i] = PbfGlyphs::encode(*tasks[G.g0 + i].name, tasks[G.g0 + i].block.range(), std::move(refs));
+	});
+	const double t4 = now_s();
+	timings_.encode_s += t4 - t3;
+	for (size_t i = 0; i < nb; i++) {
+		writer.write_file(*tasks[G.g0 + i].name + "/" + tasks[G.g0 + i].block.filename(), encoded[i]);
+		timings_.pbf_bytes += encoded[i].size();
+	}
+	timings_.write_s += now_s() - t4;
+	timings_.blocks += nb;
+	timings_.glyphs += n_jobs;
+	timings_.rasters += n_raster;
+	timings_.pixels += G.out_bytes;
+	timings_.segments += G.n_segs;
+}
+
+// Device front-end dispatcher: groups of tasks (a large font, or several small ones) go through
+// record (host pool) -> device (flatten, raster, D2H) -> encode + write (host pool), one group after the
+// other; files are written in task order; the first error aborts (manager.rs:117-121).
+// (Overlapping the stages of consecutive groups on a second thread was measured with 21 small fonts:
+// 13.7 vs 14.7 ms — the thread waiting in the HIP calls and the pool compete for the same cores, and
+// the per-font device stage is latency, not GPU work.  Not worth a second thread in the HIP runtime.)
+void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer)
+{
 	timings_ = RenderTimings{};
 	const double t_start = now_s();
-	ThreadPool &tp = pool();
-	std::vector<OSlice> slices;
-	std::vector<vgsdf_rect> rects;
-
-	for (size_t g0 = 0; g0 < tasks.size(); g0 += batch_blocks_) {
-		const size_t g1 = std::min(tasks.size(), g0 + (size_t)batch_blocks_);
-		const size_t nb = g1 - g0;
-		const double t0 = now_s();
-		slices.clear();
-		std::vector<uint32_t> slice_ci;
-		for (size_t t = g0; t < g1; t++) {
-			if (tasks[t].block.is_empty())
-				continue;
-			for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += kSlice) {
-				OSlice s;
-				s.task = (uint32_t)t;
-				slices.push_back(s);
-				slice_ci.push_back(c);
-			}
+	(void)pool();
+	FeGroup &G = fe_group_;
+	// Group size: every submission costs ~0.3 ms of latency (two read-backs, launches), so small fonts
+	// are grouped until ~32 k mapped code points (21 fixture fonts: 12.9 ms one font per group, 5.7 ms
+	// in one group); an explicit set_batch_blocks() bounds the group in blocks instead.
+	constexpr size_t kFeGlyphBudget = 32768;
+	for (size_t g0 = 0; g0 < tasks.size();) {
+		size_t g1 = g0, glyphs = 0;
+		while (g1 < tasks.size() && (batch_blocks_set_ ? g1 - g0 < (size_t)batch_blocks_ : (g1 == g0 || glyphs < kFeGlyphBudget))) {
+			glyphs += tasks[g1].block.len();
+			g1++;
 		}
-		for (Worker &w : workers_)
-			w.olocal.clear();
-		tp.run(slices.size(), [&](size_t i, unsigned wid) {
-			OSlice &s = slices[i];
-			Worker &w = workers_[wid];
-			s.worker = wid;
-			s.job0 = (uint32_t)w.olocal.jobs.size();
-			const GlyphBlock &blk = tasks[s.task].block;
-			for (uint32_t ci = slice_ci[i]; ci < slice_ci[i] + kSlice; ci++)
-				if (const FontFileEntry *f = blk.glyphs[ci])
-					Renderer::record(f->face(), blk.start_index + ci, w.olocal);
-			s.job1 = (uint32_t)w.olocal.jobs.size();
-		});
-		const double t1 = now_s();
-		timings_.tessellate_s += t1 - t0;
-
-		// merge in task order
-		uint32_t n_jobs = 0, n_cmds = 0;
-		std::vector<uint32_t> slice_cmd(slices.size());
-		for (size_t i = 0; i < slices.size(); i++) {
-			OSlice &s = slices[i];
-			const OutlineBatch &l = workers_[s.worker].olocal;
-			s.g_job = n_jobs;
-			slice_cmd[i] = n_cmds;
-			n_jobs += s.job1 - s.job0;
-			n_cmds += l.cmd_off[s.job1] - l.cmd_off[s.job0];
-		}
-		MergedOutlines &m = omerged_;
-		m.jobs.resize(n_jobs);
-		m.cmd_off.resize((size_t)n_jobs + 1);
-		m.cmds.ensure((size_t)n_cmds + 1);
-		m.scale.resize(n_jobs);
-		m.shift_x.resize(n_jobs);
-		m.cmd_off[0] = 0;
-		tp.run(slices.size(), [&](size_t i, unsigned) {
-			const OSlice &s = slices[i];
-			const OutlineBatch &l = workers_[s.worker].olocal;
-			const uint32_t lc0 = l.cmd_off[s.job0];
-			const size_t nc = l.cmd_off[s.job1] - lc0;
-			if (nc)
-				std::memcpy(m.cmds.data() + slice_cmd[i], l.cmds.data() + lc0, nc * sizeof(vgsdf_outline_cmd));
-			for (uint32_t j = s.job0; j < s.job1; j++) {
-				const uint32_t g = s.g_job + (j - s.job0);
-				m.jobs[g] = l.jobs[j];
-				m.scale[g] = l.scale[j];
-				m.shift_x[g] = l.shift_x[j];
-				m.cmd_off[g + 1] = slice_cmd[i] + (l.cmd_off[j + 1] - lc0);
-			}
-		});
-		const double t2 = now_s();
-		timings_.pack_s += t2 - t1;
-
-		uint64_t out_bytes = 0, n_segs = 0;
-		renderer.render_outlines(m.view(), rects, oout_, out_bytes, n_segs);
-		const double t3 = now_s();
-		timings_.device_s += t3 - t2;
-
-		// bitmap offsets: rasterised glyphs are packed in job order
-		std::vector<uint64_t> boff((size_t)n_jobs + 1, 0);
-		uint64_t n_raster = 0;
-		for (uint32_t g = 0; g < n_jobs; g++) {
-			const vgsdf_rect &r = rects[g];
-			GlyphJob &job = m.jobs[g];
-			job.has_raster = r.has_raster != 0;
-			job.x0 = r.x0;
-			job.y0 = r.y0;
-			job.width = r.w;
-			job.height = r.h;
-			job.x1 = r.x0 + (int32_t)r.w;
-			job.y1 = r.y0 + (int32_t)r.h;
-			job.n_segments = r.n_segments;
-			boff[g + 1] = boff[g] + (job.has_raster ? (uint64_t)r.w * r.h : 0);
-			n_raster += job.has_raster;
-		}
-		std::vector<std::pair<size_t, size_t>> span(nb, {0, 0});
-		for (size_t i = 0; i < slices.size(); i++) {
-			auto &sp = span[slices[i].task - g0];
-			if (sp.second == 0)
-				sp.first = i;
-			sp.second = i + 1;
-		}
-		std::vector<std::vector<uint8_t>> encoded(nb);
-		tp.run(nb, [&](size_t i, unsigned) {
-			std::vector<PbfGlyphRef> refs;
-			for (size_t k = span[i].first; k < span[i].second; k++) {
-				const OSlice &s = slices[k];
-				for (uint32_t j = 0; j < s.job1 - s.job0; j++) {
-					const uint32_t g = s.g_job + j;
-					const GlyphJob &job = m.jobs[g];
-					refs.push_back(job.to_pbf(job.has_raster ? oout_.data() + boff[g] : nullptr));
-				}
-			}
-			encoded[i] = PbfGlyphs::encode(*tasks[g0 + i].name, tasks[g0 + i].block.range(), std::move(refs));
-		});
-		const double t4 = now_s();
-		timings_.encode_s += t4 - t3;
-		for (size_t i = 0; i < nb; i++) {
-			writer.write_file(*tasks[g0 + i].name + "/" + tasks[g0 + i].block.filename(), encoded[i]);
-			timings_.pbf_bytes += encoded[i].size();
-		}
-		timings_.write_s += now_s() - t4;
-		timings_.blocks += nb;
-		timings_.glyphs += n_jobs;
-		timings_.rasters += n_raster;
-		timings_.pixels += out_bytes;
-		timings_.segments += n_segs;
+		G.g0 = g0;
+		G.g1 = g1;
+		g0 = g1;
+		fe_record(tasks, G);
+		const double t = now_s();
+		renderer.render_outlines(G.m.view(), G.rects, G.out, G.out_bytes, G.n_segs);
+		timings_.device_s += now_s() - t;
+		fe_encode_write(tasks, G, writer);
 	}
 	timings_.total_s = now_s() - t_start;
 }

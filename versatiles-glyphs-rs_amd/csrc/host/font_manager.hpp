@@ -120,7 +120,11 @@ public:
 	const std::map<std::string, FontWrapper> &fonts() const { return fonts_; }
 	const RenderTimings &last_timings() const { return timings_; }
 	void set_threads(unsigned n) { threads_ = n; }
-	void set_batch_blocks(unsigned n) { batch_blocks_ = n ? n : 1; }
+	void set_batch_blocks(unsigned n)
+	{
+		batch_blocks_ = n ? n : 1;
+		batch_blocks_set_ = true;
+	}
 	// true: flatten / close / scale / bbox on the GPU (device front-end, HIP renderer only);
 	// false: host tessellation.  Both produce identical bytes.
 	void set_device_front_end(bool on) { device_front_end_ = on; }
@@ -163,13 +167,26 @@ private:
 	std::unique_ptr<ThreadPool> pool_;
 	std::vector<Worker> workers_;
 	PackedBatch packed_;
-	MergedOutlines omerged_;
-	HostBuffer<uint8_t> oout_{true};
+	// device front-end: the buffers of one group of tasks (<= batch_blocks_ blocks, normally one font)
+	struct FeGroup {
+		size_t g0 = 0, g1 = 0;
+		std::vector<OSlice> slices;
+		std::vector<uint32_t> slice_ci, slice_cmd;
+		MergedOutlines m;
+		std::vector<vgsdf_rect> rects;
+		HostBuffer<uint8_t> out{true};
+		uint64_t out_bytes = 0, n_segs = 0;
+		uint32_t n_jobs = 0;
+	};
+	FeGroup fe_group_;
+	void fe_record(const std::vector<Todo> &tasks, FeGroup &G);
+	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
 	bool parallel_;
 	unsigned threads_ = 0;       // 0 = hardware_concurrency
 	unsigned batch_blocks_ = 256; // blocks per GPU submission (256 = one whole font)
+	bool batch_blocks_set_ = false; // false: the device front-end groups by glyph count instead (kFeGlyphBudget)
 	RenderTimings timings_;
 };
 
