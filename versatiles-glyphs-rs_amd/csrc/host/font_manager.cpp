@@ -114,6 +114,7 @@ bool FontWrapper::add_paths(const std::vector<std::string> &paths, std::string *
 		if (!e)
 			return false;
 		files_.push_back(std::move(e));
+		blocks_valid_ = false;
 	}
 	return true;
 }
@@ -271,8 +272,8 @@ bool FontManager::build_batch(const std::string &font_id, PackedBatch &out, std:
 		return false;
 	}
 	std::vector<Todo> tasks;
-	for (GlyphBlock &b : it->second.get_blocks())
-		tasks.push_back(Todo{&it->first, std::move(b)});
+	for (const GlyphBlock &b : it->second.blocks())
+		tasks.push_back(Todo{&it->first, b});
 	std::vector<Slice> slices;
 	tessellate_and_pack(tasks, 0, tasks.size(), slices, out);
 	ids.assign(out.n_raster, 0);
@@ -295,7 +296,7 @@ bool FontManager::record_outlines(const std::string &font_id, OutlineBatch &out,
 		return false;
 	}
 	out.clear();
-	for (const GlyphBlock &b : it->second.get_blocks())
+	for (const GlyphBlock &b : it->second.blocks())
 		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
 			if (const FontFileEntry *f = b.glyphs[ci])
 				Renderer::record(f->face(), b.start_index + ci, out);
@@ -308,8 +309,8 @@ void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 	std::vector<Todo> tasks;
 	for (const auto &[name, font] : fonts_) {
 		writer.write_directory(name + "/");
-		for (GlyphBlock &b : font.get_blocks())
-			tasks.push_back(Todo{&name, std::move(b)});
+		for (const GlyphBlock &b : font.blocks())
+			tasks.push_back(Todo{&name, b});
 	}
 	run_tasks(tasks, writer, renderer);
 }
@@ -320,7 +321,7 @@ void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const 
 	auto it = fonts_.find(font_id);
 	if (it == fonts_.end())
 		throw std::runtime_error("unknown font id " + font_id);
-	std::vector<GlyphBlock> blocks = it->second.get_blocks();
+	const std::vector<GlyphBlock> &blocks = it->second.blocks();
 	std::vector<Todo> tasks;
 	for (uint32_t start : block_starts) {
 		if (start % GLYPH_BLOCK_SIZE || start / GLYPH_BLOCK_SIZE >= blocks.size())

@@ -75,13 +75,29 @@ struct GlyphBlock {
 // wrapper.rs:15-19
 class FontWrapper {
 public:
-	void add_file(std::unique_ptr<FontFileEntry> f) { files_.push_back(std::move(f)); }
+	void add_file(std::unique_ptr<FontFileEntry> f)
+	{
+		files_.push_back(std::move(f));
+		blocks_valid_ = false;
+	}
 	bool add_paths(const std::vector<std::string> &paths, std::string *err); // wrapper.rs:31-39
 	const std::vector<std::unique_ptr<FontFileEntry>> &files() const { return files_; }
 	std::vector<GlyphBlock> get_blocks() const; // wrapper.rs:53-76: always 256 blocks
+	// the same table, built once per set of files (0.5 MiB per font: rebuilding it for every
+	// render_glyphs call was 7 % of an end-to-end run); valid until the next add_file / add_paths
+	const std::vector<GlyphBlock> &blocks() const
+	{
+		if (!blocks_valid_) {
+			blocks_ = get_blocks();
+			blocks_valid_ = true;
+		}
+		return blocks_;
+	}
 
 private:
 	std::vector<std::unique_ptr<FontFileEntry>> files_;
+	mutable std::vector<GlyphBlock> blocks_;
+	mutable bool blocks_valid_ = false;
 };
 
 struct RenderTimings {
@@ -133,7 +149,7 @@ public:
 private:
 	struct Todo {
 		const std::string *name;
-		GlyphBlock block;
+		const GlyphBlock &block; // lives in its FontWrapper's table
 	};
 	// One unit of host work: a 64-code-point slice of a task's block, tessellated into the
 	// worker's local batch; the ranges say where.
