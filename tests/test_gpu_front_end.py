@@ -134,3 +134,22 @@ def test_pbf_sha_with_device_front_end(vg, name):
     bad = [s for s, sha in want.items()
            if hashlib.sha256(w.files[f"{fid}/{s}-{int(s) + 255}.pbf"]).hexdigest() != sha]
     assert not bad, bad
+
+
+def test_front_end_argument_validation(vg, ctx):
+    """malformed command batches are refused with an error (and leave the context usable)"""
+    M, L, Z = 0, 1, 4
+    good = np.array([(0, 0, 0, 0, 10, 10, M), (0, 0, 0, 0, 400, 10, L), (0, 0, 0, 0, 400, 400, L), (0, 0, 0, 0, 10, 10, L),
+                     (0, 0, 0, 0, 0, 0, Z)], dtype=vg.OUTLINE_CMD_DTYPE)
+    sc, sh = np.array([0.024]), np.array([0.0])
+    bad_kind = good.copy()
+    bad_kind["kind"][2] = 9
+    with pytest.raises(Exception, match="unknown command kind"):
+        ctx.outlines_prepare(np.array([0, 5], np.uint32), bad_kind, sc, sh)
+    with pytest.raises(Exception, match="cmd_off"):
+        ctx.outlines_prepare(np.array([1, 5], np.uint32), good, sc, sh)
+    with pytest.raises(Exception, match="monotone"):
+        ctx.outlines_prepare(np.array([0, 5, 3], np.uint32), good, np.array([0.024, 0.024]), np.array([0.0, 0.0]))
+    rects, out_bytes, n_segs = ctx.outlines_prepare(np.array([0, 5], np.uint32), good, sc, sh)
+    assert int(rects[0]["has_raster"]) == 1 and n_segs == 3 and out_bytes == int(rects[0]["w"]) * int(rects[0]["h"])
+    assert ctx.outlines_render().size == out_bytes

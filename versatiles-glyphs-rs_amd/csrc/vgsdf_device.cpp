@@ -750,11 +750,8 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		ctx->err = "vgsdf_outlines_prepare: NULL command array";
 		return VGSDF_E_ARG;
 	}
-	for (uint32_t c = 0; c < n_cmds; c++)
-		if (in->cmds[c].kind > 4u) {
-			ctx->err = "vgsdf_outlines_prepare: unknown command kind";
-			return VGSDF_E_ARG;
-		}
+	// (the command kinds are checked further down, while the GPU already works on the upload: the
+	// kernels treat an unknown kind as a no-op, so nothing unsafe runs before the check)
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->fe)
 		ctx->fe = new (std::nothrow) FrontEnd();
@@ -817,7 +814,14 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	                             n_cmds + 1, st));
 	uint32_t *h_word = (uint32_t *)fe.h_rects.p; // pinned scratch for the read-backs
 	FE_TRY(hipMemcpyAsync(h_word, (const uint32_t *)fe.pt_off.p + n_cmds, 4, hipMemcpyDeviceToHost, st));
+	bool kinds_ok = true;
+	for (uint32_t c = 0; c < n_cmds; c++)
+		kinds_ok &= in->cmds[c].kind <= 4u;
 	FE_TRY(hipStreamSynchronize(st));
+	if (!kinds_ok) {
+		ctx->err = "vgsdf_outlines_prepare: unknown command kind";
+		return VGSDF_E_ARG;
+	}
 	tr2 = fe_now();
 	const uint32_t n_points = h_word[0];
 	fe.n_points = n_points;
