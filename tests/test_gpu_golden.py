@@ -66,6 +66,21 @@ def test_synthetic_first_64(vg, ctx):
     assert np.array_equal(out, want)
 
 
+def test_synthetic_benchmark_batch_sha(vg, ctx):
+    """config 5 at one rank's full benchmark size: 8192 outlines x 1024 segments, 40 M pixels — the
+    SHA-256 of the whole output equals the oracle's (computed on the CPU when the fixture was made);
+    and the batch composition does not matter: the first quarter rendered alone gives the same bytes."""
+    import hashlib
+    import json
+    from versatiles_glyphs_rs_amd import synthetic as S
+    g = json.loads((GOLDEN / "synthetic8192_sha256.json").read_text())
+    batch = S.make_batch(g["outlines"][0], g["outlines"][1])
+    out = ctx.render_batch(batch)
+    assert out.size == g["bytes"] and hashlib.sha256(out.tobytes()).hexdigest() == g["sha256"]
+    quarter = ctx.render_batch(S.make_batch(0, 2048))
+    assert np.array_equal(quarter, out[:quarter.size])
+
+
 def test_full_size_properties(vg, ctx):
     """Properties that need no reference, at the benchmark's full batch (Noto Sans Regular):
     the two kernel variants agree byte for byte; rendering is idempotent; glyph order inside a

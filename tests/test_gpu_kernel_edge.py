@@ -209,3 +209,30 @@ def test_argument_validation(vg, ctx):
     with pytest.raises(vg.VgsdfError) as e:
         ctx.render_batch(b)
     assert e.value.code == -1
+
+
+def test_two_contexts_on_two_threads(oracle, vg):
+    """vgsdf.h: one context per (host thread, GPU) — two threads with their own contexts (own streams,
+    own device scratch) render different batches at the same time; each gets its own bytes"""
+    import threading
+    rng = np.random.default_rng(21)
+    batches = [vg.make_batch(random_polys(rng, 60, 3, 50 + 30 * k, 28)) for k in range(2)]
+    want = [oracle.sdf_render_batch(b, oracle.BRUTE, 4)[0] for b in batches]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            c = vg.SdfContext(0)
+            for _ in range(20):
+                got[k] = c.render_batch(batches[k])
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
