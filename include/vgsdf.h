@@ -108,10 +108,12 @@ int vgsdf_batch_stats(const vgsdf_dbatch *b, vgsdf_stats *out);
  * context stream (the stream the kernel runs on); *total_ms = elapsed for all of them. */
 int vgsdf_batch_time(vgsdf_ctx *ctx, vgsdf_dbatch *b, int iters, float *total_ms);
 
-/* Selects the kernel variant: 0 = default (best verified); 1 = brute force; other values select the
- * earlier kernel generations kept for A/B measurements (all bit-exact).  Set it
- * BEFORE uploading / preparing a batch: the work list layout depends on it, and launching a
- * resident batch under a different variant fails with VGSDF_E_ARG. */
+/* Selects the kernel variant: 0 = default (bounded-group span kernel), 1 = brute force (every pixel
+ * against every segment in f64; A/B reference).  Both are bit-exact with the reference.  Any other
+ * value fails with VGSDF_E_ARG (development builds of the library, `make dev`, accept more ids for
+ * kernel experiments; those are not part of the product).  Set it BEFORE uploading / preparing a
+ * batch: the work list layout depends on it, and launching a resident batch under a different
+ * variant fails with VGSDF_E_ARG. */
 int vgsdf_set_variant(vgsdf_ctx *ctx, int variant);
 
 /*

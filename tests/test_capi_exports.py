@@ -38,3 +38,18 @@ def test_product_does_not_reference_oracle():
         txt = p.read_text()
         assert "vg_oracle" not in txt and "libvgoracle" not in txt, p
         assert not re.search(r"^\s*(import oracle|from oracle)", txt, flags=re.M), p
+
+
+def test_product_library_holds_only_product_kernels(vg):
+    """The shipped libvgsdf.so carries the default raster, the brute-force raster and the batch
+    preparation kernels; the earlier generations and the timing-only ablation instances (wrong
+    pixels) exist only in `make dev` builds."""
+    blob = vg.lib_path().read_bytes()
+    assert b"sdf_tiles_span" in blob and b"sdf_tiles_brute" in blob
+    for retired in (b"sdf_tiles_filtered", b"sdf_tiles_pk", b"sdf_tiles_hier"):
+        assert retired not in blob, retired
+    import ctypes
+    lib = ctypes.CDLL(str(vg.lib_path()))
+    lib.vgsdf_kernel_known.argtypes = [ctypes.c_int]
+    known = [k for k in range(0, 100) if lib.vgsdf_kernel_known(k)]
+    assert known == [1, 50]

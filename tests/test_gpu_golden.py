@@ -21,7 +21,7 @@ def ctx(vg):
 
 
 @pytest.mark.parametrize("name", ["fira", "noto_regular", "noto_all"])
-@pytest.mark.parametrize("variant", [0, 1, 12, 13, 22, 23, 30, 45])
+@pytest.mark.parametrize("variant", [0, 1])  # everything the product build exports: default, brute force
 def test_every_glyph_bitmap_sha(vg, ctx, name, variant):
     disp, paths = set_paths(name)
     m = vg.FontManager(True)

@@ -24,7 +24,7 @@ def run_both(oracle, vg, ctx, glyphs, mode=None):
     """glyphs: [(segs, x0, y0, w, h)] -> asserts both variants equal the oracle"""
     batch = vg.make_batch(glyphs)
     want, _ = oracle.sdf_render_batch(batch, oracle.BRUTE if mode is None else mode, 4)
-    for variant in (0, 1, 12, 13, 22, 23, 30, 45):  # default (spans), brute, and the earlier generations: scalar / packed filter never/always culled, bounded groups on tiles
+    for variant in (0, 1):  # default (bounded groups over spans) and brute force: all the product build exports
         ctx.set_variant(variant)
         got = ctx.render_batch(batch)
         diff = np.flatnonzero(got != want)
@@ -191,7 +191,7 @@ def test_synthetic_first_outlines(oracle, vg, ctx):
     from versatiles_glyphs_rs_amd import synthetic as S
     batch = S.make_batch(0, 48)
     want, _ = oracle.sdf_render_batch(batch, oracle.PRECISE, 4)
-    for variant in (0, 1, 12, 13, 22, 23, 30, 45):
+    for variant in (0, 1):
         ctx.set_variant(variant)
         assert np.array_equal(ctx.render_batch(batch), want)
     ctx.set_variant(0)
@@ -236,3 +236,12 @@ def test_two_contexts_on_two_threads(oracle, vg):
         t.join()
     assert not errs, errs
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_only_product_variants_are_selectable(vg, ctx):
+    """vgsdf_set_variant: 0 and 1 only; ablation / development ids fail with VGSDF_E_ARG."""
+    for v in (2, 12, 13, 22, 23, 30, 31, 35, 45, 50, 51, 55, 57, -1, 1000):
+        with pytest.raises(Exception):
+            ctx.set_variant(v)
+    ctx.set_variant(1)
+    ctx.set_variant(0)

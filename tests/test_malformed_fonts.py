@@ -79,3 +79,30 @@ def test_damaged_fonts_never_crash(which, seed):
                        timeout=600)
     assert p.returncode == 0, f"child died with {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
     assert "loaded" in p.stdout
+
+
+def _retag(data: bytes, old: bytes, new: bytes) -> bytes:
+    """rename a table in the sfnt directory (the table's bytes stay where they are)"""
+    n = int.from_bytes(data[4:6], "big")
+    b = bytearray(data)
+    for i in range(n):
+        rec = 12 + 16 * i
+        if bytes(b[rec:rec + 4]) == old:
+            b[rec:rec + 4] = new
+            return bytes(b)
+    raise AssertionError(f"table {old!r} not found")
+
+
+def test_cff_and_cmapless_fonts_are_refused(vg):
+    """A font whose outlines live in `CFF ` must not silently render as empty glyphs (the reference
+    renders CFF through ttf-parser's curve_to; this reader is glyf-only), and a font without a cmap
+    table fails as in the reference ("Font has no cmap table", src/font/metadata.rs:104-107)."""
+    from conftest import FIRA
+    data = Path(FIRA).read_bytes()
+    cff = _retag(_retag(data, b"glyf", b"CFF "), b"loca", b"xxxx")
+    with pytest.raises(RuntimeError, match="CFF"):
+        vg.FontManager(False).add_font_data("Fake CFF", cff)
+    with pytest.raises(RuntimeError, match="no cmap"):
+        vg.FontManager(False).add_font_data("No cmap", _retag(data, b"cmap", b"xmap"))
+    # control: the untouched font loads
+    vg.FontManager(False).add_font_data("Fira", data)

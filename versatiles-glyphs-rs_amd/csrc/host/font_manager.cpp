@@ -71,6 +71,19 @@ std::unique_ptr<FontFileEntry> FontFileEntry::create(std::vector<uint8_t> data, 
 		return nullptr;
 	}
 	e->face_ = *face;
+	if (!e->face_.has_cmap()) { // metadata.rs:104-107
+		if (err)
+			*err = "Font has no cmap table";
+		return nullptr;
+	}
+	// The reference renders CFF outlines through ttf-parser's curve_to; this reader emits `glyf` outlines
+	// only.  Refuse such a font loudly instead of writing PBFs whose glyphs are all empty.  (A font with
+	// neither glyf nor CFF outlines renders empty glyphs in the reference too: outline_glyph -> None.)
+	if (!e->face_.has_glyf_outlines() && e->face_.has_cff_outlines()) {
+		if (err)
+			*err = "CFF / CFF2 outlines are not supported (glyf fonts only)";
+		return nullptr;
+	}
 	e->codepoints_ = e->face_.unicode_codepoints();
 	return e;
 }

@@ -52,7 +52,9 @@ std::optional<Face> Face::parse(const uint8_t *data, size_t len)
 			want = 0xFFFF;
 		f.loca_entries_ = std::min(want, f.loca_.size() / (f.loca_long_ ? 4u : 2u));
 	}
+	f.has_cff_ = !find_table(file, "CFF ").empty() || !find_table(file, "CFF2").empty();
 	const Bytes cmap = find_table(file, "cmap");
+	f.has_cmap_ = cmap.has(0, 4);
 	if (cmap.has(0, 4)) {
 		const uint16_t n = cmap.u16(2);
 		for (uint16_t i = 0; i < n; i++) {

@@ -63,6 +63,12 @@ public:
 	// Emits the glyph's outline; returns false when ttf-parser would return None
 	// (callbacks already delivered stay delivered, as in the crate).
 	bool outline_glyph(uint16_t glyph_id, OutlineBuilder &builder) const;
+	// ttf-parser's `tables().cmap.is_some()`; the reference refuses fonts without one (metadata.rs:104-107)
+	bool has_cmap() const { return has_cmap_; }
+	// glyph outlines this reader can emit: `glyf` + `loca`.  A font whose outlines live in `CFF ` / `CFF2`
+	// (ttf-parser renders those through curve_to) is refused at load time instead of yielding empty glyphs.
+	bool has_glyf_outlines() const { return !glyf_.empty() && !loca_.empty(); }
+	bool has_cff_outlines() const { return has_cff_; }
 	// Sorted unique code points that a unicode cmap subtable maps to a glyph.
 	std::vector<uint32_t> unicode_codepoints() const;
 
@@ -80,7 +86,7 @@ private:
 	Bytes hmtx_, loca_, glyf_;
 	std::vector<CmapSubtable> cmap_;
 	uint16_t units_per_em_ = 0, num_glyphs_ = 0, num_hmetrics_ = 0;
-	bool loca_long_ = false;
+	bool loca_long_ = false, has_cmap_ = false, has_cff_ = false;
 	size_t loca_entries_ = 0;
 
 	friend struct GlyfWalker;

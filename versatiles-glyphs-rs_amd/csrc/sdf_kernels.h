@@ -23,6 +23,10 @@ static_assert(sizeof(GlyphDesc) == 32, "GlyphDesc must stay 32 bytes");
 // largest rows*(w+1) a tile of the filtered kernel may need (winding histogram in LDS)
 extern "C" int vgsdf_filtered_delta_cap(void);
 
+// 1 when vgsdf_launch_tiles of this build knows the kernel id (50 = span kernel, 1 = brute force; more
+// only with -DVGSDF_DEV_VARIANTS)
+extern "C" int vgsdf_kernel_known(int kernel);
+
 // tiles[i] = (glyph index, first output byte of the tile inside that glyph's bitmap)
 // list_order != 0: workgroups take tiles in list order; 0: per-XCD contiguous remap
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,

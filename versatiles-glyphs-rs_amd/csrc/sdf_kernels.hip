@@ -148,38 +148,11 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
 }
 
 // ---------------------------------------------------------------------------------------
-// Variants 12 / 13 (first filtered generation, kept for A/B): single pass over ALL segments with
-// an f32 filter; same bytes as brute force.  Its exactness argument is shared by every later kernel.
-//
-//   filter  every (pixel, segment) pair is evaluated in f32 (9 VALU ops) with coordinates
-//           relative to the glyph origin.  The value F is packed with the segment's index
-//           into one 32-bit key (F >= +0, so unsigned order of the bits is float order; the
-//           low IDX_BITS mantissa bits carry the index) and inserted into a per-lane sorted
-//           top-4 with v_min_u32 + 3 x v_med3_u32.  15 VALU ops per pair, no branches.
-//   exact   after a chunk, the best candidate and every other top-4 candidate that cannot be
-//           EXCLUDED (see below) are evaluated in f64 with the reference's exact operation
-//           order, straight from LDS.  If even the 4th candidate cannot be excluded the lane
-//           rescans the chunk against a verified key threshold (rare: >= 4 near-ties).
-//   sign    per (segment, row) crossing -> a per-row column histogram in LDS (what the
-//           reference's sorted crossing sweep computes, renderer_precise.rs:41-67); prefix
-//           sums give the winding number of every pixel.  Exact f64 compares only.
-//
-// Why it is exact.  C(p,s): the reference's f64 value; D: the real value; Ft: the f32 value;
-// Fk <= Ft <= Fk (1 + 2^-14): the key's truncated value.  With |Ft - D| <= h(Ft) and
-// |C - D| <= e64 (bounds derived in DESIGN.md):
-//      min_s C  <=  C(s1)  <=  U := Fk1 (1+2^-14) + h(Fk1 (1+2^-14)) + e64        (s1 = smallest key)
-//      C(s)     >=  L(s) := Fk(s) - h(Fk(s) (1+2^-14)) - e64.
-// A segment with L(s) > U can therefore not attain the minimum; L is increasing in Fk on
-// the range where that can happen, so once the k-th smallest key is excluded all larger keys
-// are.  The minimum of C over the non-excluded segments is the minimum over all segments,
-// bit for bit.  Non-finite inputs or |coordinates| >= 1e6 px make U = +inf (nothing is
-// excluded, the lane rescans everything exactly).
+// Shared pieces of the filtered kernels (the default kernel at the end of this file, and the earlier
+// generations kept in dev/sdf_retired.inc for development builds).
 // ---------------------------------------------------------------------------------------
-constexpr int IDX_BITS = 8;
-constexpr int FCHUNK = 1 << IDX_BITS; // 512 segments per LDS stage: 20 B filter + 32 B exact each
-constexpr uint32_t IDX_MASK = FCHUNK - 1;
-constexpr int DELTA_CAP = 2048;       // winding histogram cells per tile: rows * (w + 1)
-constexpr float KEY_SLACK = 1.0f + 2.0f / (float)(1 << (23 - IDX_BITS)) * 0.5f + 1.0f / 4194304.0f; // >= (1 + 2^-(23-IDX_BITS))(1 + 2^-23)
+constexpr int FCHUNK = 256;      // segments per LDS stage: 20 B filter record + 32 B exact end points each
+constexpr int DELTA_CAP = 2048;  // winding histogram cells per span: rows * (w + 1)
 
 // smallest integer n in [A, B] with (double)n + c >= v   (B if none): exact f64 compares
 __device__ __forceinline__ int first_ge(double v, double c, int A, int B)
@@ -195,312 +168,12 @@ __device__ __forceinline__ int first_ge(double v, double c, int A, int B)
 	return n;
 }
 
-// f32 filter: squared distance from the pixel centre (rpx,rpy) to the segment starting at
-// (a.x,a.y) with UNIT direction (a.z,a.w) and length len — all relative to the glyph origin.
-__device__ __forceinline__ float filter_dist_sq(float rpx, float rpy, float4 a, float len)
-{
-	const float pvx = rpx - a.x, pvy = rpy - a.y;
-	const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(pvy, a.w, pvx * a.z), 0.0f, len);
-	const float ex = __builtin_fmaf(-t, a.z, pvx), ey = __builtin_fmaf(-t, a.w, pvy);
-	return __builtin_fmaf(ey, ey, ex * ex);
-}
-
-// median of three unsigned values: one v_med3_u32
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
-{
-	uint32_t r;
-	asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-	return r;
-}
-
 // h(F): bound on |Ft - D| for a filter value F, coordinates bounded by M:
 // 64 u M sqrt(F) + 32 u F + 2^-34 M^2 with u = 2^-24, evaluated with upward slack.
 __device__ __forceinline__ float filter_err(float F, float M)
 {
 	return 1.001f * (3.814697265625e-06f * M * __builtin_sqrtf(F) + 1.9073486328125e-06f * F +
 	                 5.820766091346741e-11f * M * M);
-}
-
-// ABL: timing-only ablation mask (0 in production; non-zero variants give WRONG pixels):
-// 1 no winding pass, 2 no filter loop, 4 no exact evaluation, 16 no prefix loop
-template <int ABL, bool CULL>
-__global__ __launch_bounds__(TPB) void sdf_tiles_filtered(const GlyphDesc *__restrict__ glyphs,
-                                                          const uint2 *__restrict__ tiles,
-                                                          uint32_t n_tiles,
-                                                          const double *__restrict__ seg_sx,
-                                                          const double *__restrict__ seg_sy,
-                                                          const double *__restrict__ seg_ex,
-                                                          const double *__restrict__ seg_ey,
-                                                          uint8_t *__restrict__ out)
-{
-	__shared__ float4 s_f[FCHUNK];  // (vx, vy, nx, ny) f32: start relative to (x0, y0), unit direction
-	__shared__ __attribute__((aligned(16))) float s_len[FCHUNK]; // segment length; direction (0,0) and length 0 when degenerate
-	__shared__ double s_vx[FCHUNK], s_vy[FCHUNK], s_wx[FCHUNK], s_wy[FCHUNK]; // exact endpoints
-	__shared__ int s_delta[DELTA_CAP];
-	__shared__ uint32_t s_mbits;
-	__shared__ __attribute__((aligned(8))) uint16_t s_list[TPB / 64][FCHUNK]; // per-wave candidate lists (CULL)
-
-	const uint32_t tid = threadIdx.x;
-	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-	const uint2 t = tiles[tile];
-	const GlyphDesc g = glyphs[t.x];
-	const uint32_t npix = g.w * g.h;
-	const uint32_t o = t.y + tid;
-	const bool active = o < npix;
-	const uint32_t oc = active ? o : npix - 1;
-	const uint32_t row = oc / g.w;
-	const uint32_t x = oc - row * g.w;
-	const uint32_t y = g.h - 1 - row;
-	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
-	const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
-	const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
-
-	// rows of the bitmap this tile touches: output rows [r_first, r_last] = y in [y_lo, y_hi]
-	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
-	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
-	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
-	const uint32_t stride = g.w + 1;
-	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
-
-	for (uint32_t i = tid; i < n_delta; i += TPB)
-		s_delta[i] = 0;
-
-	const float wh = (float)max(g.w, g.h);
-	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
-	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
-	const bool cull_pays = CULL; // the host routes only tiles of large glyphs to the CULL instance
-	double best = __builtin_huge_val(); // rtree_segments.rs:57
-	float ub = __builtin_inff();        // CULL: squared distance to the nearest sampled vertex so far
-
-	auto exact_lds = [&](uint32_t i) {
-		const double vx = s_vx[i], vy = s_vy[i], wx = s_wx[i], wy = s_wy[i];
-		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
-		const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
-		best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
-	};
-
-	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
-		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
-		__syncthreads(); // previous chunk fully consumed (and s_delta zeroed on the first trip)
-		if (tid == 0)
-			s_mbits = __float_as_uint(wh);
-		__syncthreads();
-
-		// ---- stage: exact endpoints, f32 filter data, coordinate bound, row crossings ----
-		for (uint32_t i = tid; i < cnt; i += TPB) {
-			const uint32_t s = g.seg_off + c0 + i;
-			const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
-			s_vx[i] = vx;
-			s_vy[i] = vy;
-			s_wx[i] = wx;
-			s_wy[i] = wy;
-			const double dx = wx - vx, dy = wy - vy;
-			const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
-			const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
-			const float len = (float)sqrt(dx * dx + dy * dy);
-			const bool ok = len > 1e-12f && len < 1e30f;
-			const float rl = ok ? 1.0f / len : 0.0f;
-			s_f[i] = make_float4((float)rvx, (float)rvy, (float)dx * rl, (float)dy * rl);
-			s_len[i] = ok ? len : 0.0f;
-			const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
-			float mf = (float)m * 1.000001f;                // round up
-			mf = mf >= 0.0f ? mf : __builtin_inff();        // NaN -> inf ("no usable bound")
-			atomicMax(&s_mbits, __float_as_uint(mf));       // non-negative floats order like uints
-			// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
-			if (!(ABL & 1) && vy != wy) {
-				const bool up = vy < wy;
-				const double lo = up ? vy : wy, hi = up ? wy : vy;
-				const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
-				const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
-				for (int yy = ya; yy < yb; yy++) {
-					const double pyy = (double)yy + y0c;
-					const double tc = (pyy - vy) / dy;
-					const double xc = vx + tc * dx;               // :45-46 / :48-49
-					const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
-					if (k < (int)g.w)
-						atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
-				}
-			}
-		}
-		__syncthreads();
-
-		// ---- cull (per wave): which segments of the chunk can matter for THIS wave's pixels ----
-		// A segment is dropped only if its distance to every pixel of the wave's strip exceeds
-		// R, with R^2 >= min(UB, SAT^2) for every lane: UB = squared distance to some vertex
-		// (>= the true minimum, and that vertex's own segment is within R, so it stays), and
-		// SAT = 6.2 px (beyond 5.97 px outside / 2.02 px inside the byte is saturated whatever
-		// the minimum is: the reference's own +-8 px candidate rule, rtree_segments.rs:47-53).
-		uint32_t n_list = cnt;
-		const uint32_t wv = tid >> 6, lane = tid & 63;
-		const float Mc = __uint_as_float(s_mbits);
-		bool use_list = false;
-		if (cull_pays && Mc < 4096.0f) { // beyond that the f32 box test has no useful margin
-			use_list = true;
-			for (uint32_t j = 0; j < cnt; j += 8) { // every 8th start vertex
-				const float4 a = s_f[j];
-				const float ddx = rpx - a.x, ddy = rpy - a.y;
-				const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
-				ub = d2 < ub ? d2 : ub;
-			}
-			float r2 = ub < 38.44f ? ub : 38.44f; // SAT^2 = 6.2^2
-			for (int sh = 32; sh > 0; sh >>= 1) {
-				const float other = __shfl_xor(r2, sh);
-				r2 = other > r2 ? other : r2;
-			}
-			const float R2 = r2 * 1.01f + 0.02f; // covers the f32 rounding of UB and of the boxes (M < 4096)
-			const float delta = 4.0e-6f * Mc;
-			// the strip of pixels this wave owns (wave-uniform)
-			const uint32_t row_a = __builtin_amdgcn_readlane(row, 0), row_b = __builtin_amdgcn_readlane(row, 63);
-			const uint32_t x_a = __builtin_amdgcn_readlane(x, 0), x_b = __builtin_amdgcn_readlane(x, 63);
-			const float X0 = (row_a == row_b ? (float)x_a : 0.0f) + 0.5f;
-			const float X1 = (row_a == row_b ? (float)x_b : (float)(g.w - 1)) + 0.5f;
-			const float Y0 = (float)(g.h - 1 - row_b) + 0.5f, Y1 = (float)(g.h - 1 - row_a) + 0.5f;
-			n_list = 0;
-			for (uint32_t base = 0; base < cnt; base += 64) {
-				const uint32_t i = base + lane;
-				const bool valid = i < cnt;
-				const float4 a = s_f[valid ? i : 0];
-				const float len = s_len[valid ? i : 0];
-				const float wx = __builtin_fmaf(len, a.z, a.x), wy = __builtin_fmaf(len, a.w, a.y);
-				float gx = fmaxf(fminf(a.x, wx) - X1, X0 - fmaxf(a.x, wx)) - delta;
-				float gy = fmaxf(fminf(a.y, wy) - Y1, Y0 - fmaxf(a.y, wy)) - delta;
-				gx = gx > 0.0f ? gx : 0.0f;
-				gy = gy > 0.0f ? gy : 0.0f;
-				const float lb = __builtin_fmaf(gy, gy, gx * gx);
-				const bool pass = valid && !(lb > R2); // NaN passes
-				const unsigned long long m = __ballot(pass);
-				const uint32_t pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-				if (pass)
-					s_list[wv][pos] = (uint16_t)i;
-				n_list += (uint32_t)__builtin_popcountll(m);
-			}
-			__builtin_amdgcn_wave_barrier();
-		}
-
-		// ---- filter: sorted top-4 of (F | index) keys over the listed segments ----
-		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
-		uint32_t key_mask = ~IDX_MASK;
-		asm volatile("" : "+v"(key_mask)); // keep it in a VGPR (one SGPR/literal operand per VOP3 on gfx9)
-		auto insert = [&](uint32_t key) { // sorted quadruple: clamp(key, k_{j-1}, k_j) = med3
-			k4 = umed3(k3, k4, key);
-			k3 = umed3(k2, k3, key);
-			k2 = umed3(k1, k2, key);
-			k1 = min(k1, key);
-		};
-		auto consider = [&](float4 a, float len, uint32_t i) { // i wave-uniform (SGPR)
-			const float F = filter_dist_sq(rpx, rpy, a, len);
-			uint32_t key; // (F & ~IDX_MASK) | i in one VALU op
-			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(F)), "v"(key_mask), "s"(i));
-			insert(key);
-		};
-		auto consider_v = [&](uint32_t i) { // i in a VGPR (read from the candidate list)
-			const float F = filter_dist_sq(rpx, rpy, s_f[i], s_len[i]);
-			uint32_t key;
-			asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(F)), "v"(key_mask), "v"(i));
-			insert(key);
-		};
-		const uint32_t cnt_f = (ABL & 2) ? min(n_list, 4u) : n_list;
-		const uint32_t cnt4 = cnt_f & ~3u;
-		if (use_list) {
-			const uint2 *lst = reinterpret_cast<const uint2 *>(&s_list[wv][0]);
-			for (uint32_t j = 0; j < cnt4; j += 4) {
-				const uint2 ii = lst[j >> 2];
-				consider_v(ii.x & 0xFFFFu);
-				consider_v(ii.x >> 16);
-				consider_v(ii.y & 0xFFFFu);
-				consider_v(ii.y >> 16);
-			}
-			for (uint32_t j = cnt4; j < cnt_f; j++)
-				consider_v(s_list[wv][j]);
-		} else {
-			const float4 *s_len4 = reinterpret_cast<const float4 *>(s_len);
-			for (uint32_t i = 0; i < cnt4; i += 4) {
-				const float4 a0 = s_f[i], a1 = s_f[i + 1], a2 = s_f[i + 2], a3 = s_f[i + 3];
-				const float4 l = s_len4[i >> 2];
-				consider(a0, l.x, i);
-				consider(a1, l.y, i + 1);
-				consider(a2, l.z, i + 2);
-				consider(a3, l.w, i + 3);
-			}
-			for (uint32_t i = cnt4; i < cnt_f; i++)
-				consider(s_f[i], s_len[i], i);
-		}
-
-		if (!(ABL & 4) && n_list > 0) {
-			// ---- exact evaluation of the candidates that cannot be excluded ----
-			const float M = Mc;
-			const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
-			const float f1 = __uint_as_float(k1 & ~IDX_MASK) * KEY_SLACK;
-			float U = f1 + filter_err(f1, M) + e64;
-			if (!(M < 1.0e6f) || !(U >= 0.0f))
-				U = __builtin_inff();
-			auto excluded = [&](uint32_t key) {
-				const float fk = __uint_as_float(key & ~IDX_MASK);
-				return fk - filter_err(fk * KEY_SLACK, M) - e64 > U; // false for NaN / inf U
-			};
-			exact_lds(k1 & IDX_MASK); // n_list >= 1, so k1 is a real key
-			if (n_list >= 2 && !excluded(k2))
-				exact_lds(k2 & IDX_MASK);
-			if (n_list >= 3 && !excluded(k3))
-				exact_lds(k3 & IDX_MASK);
-			if (n_list >= 4 && !excluded(k4)) {
-				exact_lds(k4 & IDX_MASK);
-				// Four near-ties: more may hide behind them.  Rescan the chunk against a
-				// key threshold Tk with L(Tk) > U (L increasing above it): fixed-point
-				// iteration for the crossing, pushed up, then VERIFIED; if the check fails
-				// nothing is excluded (Tk = inf).
-				float Tk = U + e64;
-				for (int it = 0; it < 3; it++)
-					Tk = U + e64 + filter_err(Tk * KEY_SLACK, M);
-				Tk = Tk * 1.001f + 1e-30f;
-				if (!(Tk - filter_err(Tk * KEY_SLACK, M) - e64 > U))
-					Tk = __builtin_inff();
-				for (uint32_t j = 0; j < ((ABL & 8) ? 0u : n_list); j++) {
-					const uint32_t i = use_list ? (uint32_t)s_list[wv][j] : j;
-					const float F = filter_dist_sq(rpx, rpy, s_f[i], s_len[i]);
-					const float fk = __uint_as_float(__float_as_uint(F) & ~IDX_MASK);
-					if (!(fk > Tk))
-						exact_lds(i);
-				}
-			}
-		}
-	}
-
-	if (active) {
-		// winding number = prefix sum of the row's histogram up to this column
-		int wn = 0;
-		const int *drow = s_delta + (row - r_first) * stride;
-		for (uint32_t k = 0; k <= ((ABL & 16) ? 0u : x); k++)
-			wn += drow[k];
-		out[g.out_off + o] = quantise(best, wn != 0);
-	}
-}
-
-// ---------------------------------------------------------------------------------------
-// Variants 22 / 23 (second generation, kept for A/B): same algorithm and the same exactness
-// argument as sdf_tiles_filtered, with the f32 filter evaluated for TWO segments per VALU
-// instruction (v_pk_add/mul/fma_f32 issue at the scalar rate on gfx950 — measured,
-// tools/ubench/valu_rate.hip — so the 9 filter ops cost 4.5 issue slots per segment).
-//
-// Filter record (SoA in LDS, read as float4 = two packed pairs per array):
-//   v (start, relative to the glyph origin), d = w - v, inv = 1/|d|^2 (0 when degenerate)
-//   t = clamp(((p-v).d) * inv, 0, 1)  [v_pk_mul_f32 ... clamp],  F = |(p-v) - t d|^2.
-// Error bound: the record's end points are within 4.25uM + u|d| <= 7.1uM of the true ones
-// (tighter than the unit-direction form), the parameter error is again second order, so
-// h(F) = 64uM sqrt(F) + 32uF + 2^-34 M^2 holds with more slack.
-// CULL: each wave compacts the records that can matter for its strip into its own SoA
-// arrays (plus their indices) and then runs the very same packed loop over them.
-// ---------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 pk_filter(f2 rpx, f2 rpy, f2 vx, f2 vy, f2 dx, f2 dy, f2 inv)
-{
-	const f2 pvx = rpx - vx, pvy = rpy - vy;
-	const f2 dot = __builtin_elementwise_fma(pvy, dy, pvx * dx);
-	f2 t;
-	asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(dot), "v"(inv)); // clamp to [0,1]; NaN -> 0
-	const f2 ex = __builtin_elementwise_fma(-t, dx, pvx), ey = __builtin_elementwise_fma(-t, dy, pvy);
-	return __builtin_elementwise_fma(ey, ey, ex * ex);
 }
 
 __device__ __forceinline__ float sc_filter(float rpx, float rpy, float vx, float vy, float dx, float dy, float inv)
@@ -511,724 +184,11 @@ __device__ __forceinline__ float sc_filter(float rpx, float rpy, float vx, float
 	return __builtin_fmaf(ey, ey, ex * ex);
 }
 
-template <int ABL, bool CULL, int PPL>
-__global__ __launch_bounds__(TPB / PPL) void sdf_tiles_pk(const GlyphDesc *__restrict__ glyphs,
-                                                          const uint2 *__restrict__ tiles, uint32_t n_tiles,
-                                                          const double *__restrict__ seg_sx,
-                                                          const double *__restrict__ seg_sy,
-                                                          const double *__restrict__ seg_ex,
-                                                          const double *__restrict__ seg_ey,
-                                                          uint8_t *__restrict__ out)
-{
-	// PPL pixels per lane (adjacent output bytes): every LDS broadcast read of a segment
-	// record then serves 64 * PPL pixels.  With PPL = 1 the grouped loop is LDS-bandwidth
-	// bound (10 ds_read_b128 per 8 segments per wave); PPL = 2 halves that traffic.
-	constexpr int NT = TPB / PPL; // threads per workgroup; the tile is still TPB pixels
-	constexpr int NW = NT / 64;
-	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
-	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
-	__shared__ int s_delta[DELTA_CAP];
-	__shared__ uint32_t s_mbits;
-	// CULL: per-wave compacted records + their chunk indices
-	__shared__ __attribute__((aligned(16))) float c_rec[CULL ? NW : 1][5][CULL ? FCHUNK : 4];
-	__shared__ __attribute__((aligned(16))) uint32_t c_idx[CULL ? NW : 1][CULL ? FCHUNK : 4];
-
-	const uint32_t tid = threadIdx.x;
-	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-	const uint2 t = tiles[tile];
-	const GlyphDesc g = glyphs[t.x];
-	const uint32_t npix = g.w * g.h;
-	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
-
-	uint32_t o[PPL], row[PPL], x[PPL];
-	bool active[PPL];
-	double px[PPL], py[PPL];
-	float rpx[PPL], rpy[PPL];
-	f2 rpx2[PPL], rpy2[PPL];
-#pragma unroll
-	for (int p = 0; p < PPL; p++) {
-		o[p] = t.y + tid * PPL + p;
-		active[p] = o[p] < npix;
-		const uint32_t oc = active[p] ? o[p] : npix - 1;
-		row[p] = oc / g.w;
-		x[p] = oc - row[p] * g.w;
-		const uint32_t y = g.h - 1 - row[p];
-		px[p] = (double)x[p] + x0c; // renderer_precise.rs:27-28,34,62
-		py[p] = (double)y + y0c;
-		rpx[p] = (float)x[p] + 0.5f; // pixel centre relative to (x0,y0)
-		rpy[p] = (float)y + 0.5f;
-		rpx2[p] = f2{rpx[p], rpx[p]};
-		rpy2[p] = f2{rpy[p], rpy[p]};
-	}
-
-	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
-	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
-	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
-	const uint32_t stride = g.w + 1;
-	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
-	for (uint32_t i = tid; i < n_delta; i += NT)
-		s_delta[i] = 0;
-
-	const float wh = (float)max(g.w, g.h);
-	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
-	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
-	double best[PPL];
-	float ub[PPL]; // CULL: squared distance to the nearest sampled vertex so far
-#pragma unroll
-	for (int p = 0; p < PPL; p++) {
-		best[p] = __builtin_huge_val(); // rtree_segments.rs:57
-		ub[p] = __builtin_inff();
-	}
-	const uint32_t wv = tid >> 6, lane = tid & 63;
-
-	auto exact_lds = [&](int p, uint32_t i) {
-		const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
-		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
-		const double d2 = exact_dist_sq(px[p], py[p], vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
-		best[p] = d2 < best[p] ? d2 : best[p]; // rtree_segments.rs:60-62
-	};
-
-	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
-		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
-		__syncthreads(); // previous chunk fully consumed (and s_delta zeroed on the first trip)
-		if (tid == 0)
-			s_mbits = __float_as_uint(wh);
-		__syncthreads();
-
-		// ---- stage: exact endpoints, f32 filter records, coordinate bound, row crossings ----
-		for (uint32_t i = tid; i < FCHUNK; i += NT) {
-			if (i >= cnt) { // pad the chunk with records that can never win (F = 2e36)
-				s_vx[i] = 1.0e18f;
-				s_vy[i] = 1.0e18f;
-				s_dx[i] = 0.0f;
-				s_dy[i] = 0.0f;
-				s_inv[i] = 0.0f;
-				continue;
-			}
-			const uint32_t s = g.seg_off + c0 + i;
-			const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
-			e_vx[i] = vx;
-			e_vy[i] = vy;
-			e_wx[i] = wx;
-			e_wy[i] = wy;
-			const double dx = wx - vx, dy = wy - vy;
-			const double l2 = dx * dx + dy * dy;
-			const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
-			const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
-			s_vx[i] = (float)rvx;
-			s_vy[i] = (float)rvy;
-			s_dx[i] = (float)dx;
-			s_dy[i] = (float)dy;
-			s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
-			const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
-			float mf = (float)m * 1.000001f;          // round up
-			mf = mf >= 0.0f ? mf : __builtin_inff();  // NaN -> inf ("no usable bound")
-			atomicMax(&s_mbits, __float_as_uint(mf)); // non-negative floats order like uints
-			// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
-			if (!(ABL & 1) && vy != wy) {
-				const bool up = vy < wy;
-				const double lo = up ? vy : wy, hi = up ? wy : vy;
-				const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
-				const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
-				for (int yy = ya; yy < yb; yy++) {
-					const double pyy = (double)yy + y0c;
-					const double tc = (pyy - vy) / dy;
-					const double xc = vx + tc * dx;               // :45-46 / :48-49
-					const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
-					if (k < (int)g.w)
-						atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
-				}
-			}
-		}
-		__syncthreads();
-		const float Mc = __uint_as_float(s_mbits);
-		const bool sane = Mc < 1.0e6f; // else: no usable f32 bound -> every segment is evaluated exactly
-
-		// ---- which arrays does this wave scan? the chunk's, or its own compacted copy ----
-		const float *a_vx = s_vx, *a_vy = s_vy, *a_dx = s_dx, *a_dy = s_dy, *a_inv = s_inv;
-		uint32_t n_list = cnt;
-		bool use_list = false;
-		if (CULL && Mc < 4096.0f) {
-			// A segment is dropped only if its distance to every pixel of the wave's strip exceeds
-			// R, with R^2 >= min(UB, SAT^2) for every pixel: UB = squared distance to some vertex
-			// (>= the true minimum, and that vertex's own segment is within R, so it stays), and
-			// SAT = 6.2 px (beyond 5.97 px outside / 2.02 px inside the byte is saturated whatever
-			// the minimum is: the reference's own +-8 px candidate rule, rtree_segments.rs:47-53).
-			use_list = true;
-			float r2 = 0.0f;
-			for (uint32_t j = 0; j < cnt; j += 8) { // every 8th start vertex
-				const float svx = s_vx[j], svy = s_vy[j];
-#pragma unroll
-				for (int p = 0; p < PPL; p++) {
-					const float ddx = rpx[p] - svx, ddy = rpy[p] - svy;
-					const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
-					ub[p] = d2 < ub[p] ? d2 : ub[p];
-				}
-			}
-#pragma unroll
-			for (int p = 0; p < PPL; p++) {
-				const float c = ub[p] < 38.44f ? ub[p] : 38.44f; // SAT^2 = 6.2^2
-				r2 = c > r2 ? c : r2;
-			}
-			for (int sh = 32; sh > 0; sh >>= 1) {
-				const float other = __shfl_xor(r2, sh);
-				r2 = other > r2 ? other : r2;
-			}
-			const float R2 = r2 * 1.01f + 0.02f; // covers the f32 rounding of UB and of the boxes (M < 4096)
-			const float delta = 4.0e-6f * Mc;
-			// the strip of pixels this wave owns (wave-uniform): first pixel of lane 0 .. last of lane 63
-			const uint32_t row_a = __builtin_amdgcn_readlane(row[0], 0), row_b = __builtin_amdgcn_readlane(row[PPL - 1], 63);
-			const uint32_t x_a = __builtin_amdgcn_readlane(x[0], 0), x_b = __builtin_amdgcn_readlane(x[PPL - 1], 63);
-			const float X0 = (row_a == row_b ? (float)x_a : 0.0f) + 0.5f;
-			const float X1 = (row_a == row_b ? (float)x_b : (float)(g.w - 1)) + 0.5f;
-			const float Y0 = (float)(g.h - 1 - row_b) + 0.5f, Y1 = (float)(g.h - 1 - row_a) + 0.5f;
-			n_list = 0;
-			for (uint32_t base = 0; base < cnt; base += 64) {
-				const uint32_t i = base + lane;
-				const bool valid = i < cnt;
-				const uint32_t ic = valid ? i : 0;
-				const float vx = s_vx[ic], vy = s_vy[ic], dx = s_dx[ic], dy = s_dy[ic], inv = s_inv[ic];
-				const float wx = vx + dx, wy = vy + dy;
-				float gx = fmaxf(fminf(vx, wx) - X1, X0 - fmaxf(vx, wx)) - delta;
-				float gy = fmaxf(fminf(vy, wy) - Y1, Y0 - fmaxf(vy, wy)) - delta;
-				gx = gx > 0.0f ? gx : 0.0f;
-				gy = gy > 0.0f ? gy : 0.0f;
-				const float lb = __builtin_fmaf(gy, gy, gx * gx);
-				const bool pass = valid && !(lb > R2); // NaN passes
-				const unsigned long long m = __ballot(pass);
-				const uint32_t pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-				if (pass) {
-					c_rec[wv][0][pos] = vx;
-					c_rec[wv][1][pos] = vy;
-					c_rec[wv][2][pos] = dx;
-					c_rec[wv][3][pos] = dy;
-					c_rec[wv][4][pos] = inv;
-					c_idx[wv][pos] = i;
-				}
-				n_list += (uint32_t)__builtin_popcountll(m);
-			}
-			// pad the compacted arrays to a multiple of 8 (one group) with records that never win
-			if (lane < 8) {
-				const uint32_t pos = n_list + lane;
-				if (pos < ((n_list + 7u) & ~7u)) {
-					c_rec[wv][0][pos] = 1.0e18f;
-					c_rec[wv][1][pos] = 1.0e18f;
-					c_rec[wv][2][pos] = 0.0f;
-					c_rec[wv][3][pos] = 0.0f;
-					c_rec[wv][4][pos] = 0.0f;
-					c_idx[wv][pos] = 0;
-				}
-			}
-			__builtin_amdgcn_wave_barrier();
-			a_vx = c_rec[wv][0];
-			a_vy = c_rec[wv][1];
-			a_dx = c_rec[wv][2];
-			a_dy = c_rec[wv][3];
-			a_inv = c_rec[wv][4];
-		}
-
-		// ---- level 1: per group of 8 segments keep only the smallest F; sorted top-3 of the
-		// group minima (F | group id).  Selection ops (min/med3: half rate, serially dependent)
-		// drop from 4 per segment to 1 per segment; the packed filter does the rest. ----
-		constexpr uint32_t GRP = 8, GMASK = (FCHUNK / GRP) - 1; // 32 groups per chunk -> 5 id bits
-		constexpr float GSLACK = 1.0f + 1.0f / 262144.0f + 1.0f / 4194304.0f; // >= (1 + 2^-18)(1 + 2^-23)
-		const uint32_t n8 = (n_list + GRP - 1) & ~(GRP - 1); // padded records (F = 2e36) never win
-		const uint32_t n_groups = n8 / GRP;
-		uint32_t k1[PPL], k2[PPL], k3[PPL];
-#pragma unroll
-		for (int p = 0; p < PPL; p++)
-			k1[p] = k2[p] = k3[p] = 0xFFFFFFFFu;
-		uint32_t gmask_v = ~GMASK;
-		asm volatile("" : "+v"(gmask_v)); // VGPR operand (one SGPR/literal per VOP3 on gfx9)
-		const float4 *q_vx = reinterpret_cast<const float4 *>(a_vx), *q_vy = reinterpret_cast<const float4 *>(a_vy);
-		const float4 *q_dx = reinterpret_cast<const float4 *>(a_dx), *q_dy = reinterpret_cast<const float4 *>(a_dy);
-		const float4 *q_inv = reinterpret_cast<const float4 *>(a_inv);
-		auto umin3 = [](uint32_t a, uint32_t b, uint32_t c) {
-			uint32_t r;
-			asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-			return r;
-		};
-		for (uint32_t gi = 0; gi < ((ABL & 2) ? min(n_groups, 1u) : n_groups); gi++) {
-			const float4 vxa = q_vx[2 * gi], vya = q_vy[2 * gi], dxa = q_dx[2 * gi], dya = q_dy[2 * gi], iva = q_inv[2 * gi];
-			const float4 vxb = q_vx[2 * gi + 1], vyb = q_vy[2 * gi + 1], dxb = q_dx[2 * gi + 1], dyb = q_dy[2 * gi + 1],
-			             ivb = q_inv[2 * gi + 1];
-#pragma unroll
-			for (int p = 0; p < PPL; p++) {
-				const f2 Fa = pk_filter(rpx2[p], rpy2[p], f2{vxa.x, vxa.y}, f2{vya.x, vya.y}, f2{dxa.x, dxa.y}, f2{dya.x, dya.y}, f2{iva.x, iva.y});
-				const f2 Fb = pk_filter(rpx2[p], rpy2[p], f2{vxa.z, vxa.w}, f2{vya.z, vya.w}, f2{dxa.z, dxa.w}, f2{dya.z, dya.w}, f2{iva.z, iva.w});
-				const f2 Fc = pk_filter(rpx2[p], rpy2[p], f2{vxb.x, vxb.y}, f2{vyb.x, vyb.y}, f2{dxb.x, dxb.y}, f2{dyb.x, dyb.y}, f2{ivb.x, ivb.y});
-				const f2 Fd = pk_filter(rpx2[p], rpy2[p], f2{vxb.z, vxb.w}, f2{vyb.z, vyb.w}, f2{dxb.z, dxb.w}, f2{dyb.z, dyb.w}, f2{ivb.z, ivb.w});
-				// F >= +0: unsigned order of the bits is float order; NaN bits sort above +inf
-				uint32_t m = umin3(__float_as_uint(Fa.x), __float_as_uint(Fa.y), __float_as_uint(Fb.x));
-				m = umin3(m, __float_as_uint(Fb.y), __float_as_uint(Fc.x));
-				m = umin3(m, __float_as_uint(Fc.y), __float_as_uint(Fd.x));
-				m = min(m, __float_as_uint(Fd.y));
-				uint32_t gkey;
-				asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(gkey) : "v"(m), "v"(gmask_v), "s"(gi));
-				k3[p] = umed3(k2[p], k3[p], gkey); // sorted triple: clamp(key, k_{j-1}, k_j)
-				k2[p] = umed3(k1[p], k2[p], gkey);
-				k1[p] = min(k1[p], gkey);
-			}
-		}
-
-		if (!(ABL & 4) && n_list > 0) {
-			const float M = Mc;
-			const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
-#pragma unroll
-			for (int p = 0; p < PPL; p++) {
-				// U >= min over all segments of C: the best group's minimum is a real segment's F
-				const float f1 = __uint_as_float(k1[p] & ~GMASK) * GSLACK;
-				float U = f1 + filter_err(f1, M) + e64;
-				if (!sane || !(U >= 0.0f))
-					U = __builtin_inff();
-				auto excluded = [&](float fk) { // fk <= the true filter value <= fk * GSLACK
-					return fk - filter_err(fk * GSLACK, M) - e64 > U; // false for NaN / inf U
-				};
-				bool rescan = !sane; // keys are meaningless without a bound: evaluate everything
-				if (sane) {
-					// ---- level 2: inside every group whose minimum cannot be excluded, sorted top-4
-					// of (F | position) over its 8 members (lane-divergent LDS reads) ----
-					uint32_t q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu, q3 = 0xFFFFFFFFu, q4 = 0xFFFFFFFFu;
-					const bool g2 = n_groups >= 2 && !excluded(__uint_as_float(k2[p] & ~GMASK));
-					const bool g3 = n_groups >= 3 && !excluded(__uint_as_float(k3[p] & ~GMASK));
-					if (g3 && n_groups > 3)
-						rescan = true; // a 4th group (and more) may hold candidates too
-					for (uint32_t j = 0; j < 3; j++) {
-						const bool take = j == 0 || (j == 1 ? g2 : g3);
-						if (take && !rescan) {
-							const uint32_t gbase = ((j == 0 ? k1[p] : (j == 1 ? k2[p] : k3[p])) & GMASK) * GRP;
-							for (uint32_t mth = 0; mth < GRP; mth++) {
-								const uint32_t pos = gbase + mth;
-								const float F = sc_filter(rpx[p], rpy[p], a_vx[pos], a_vy[pos], a_dx[pos], a_dy[pos], a_inv[pos]);
-								const uint32_t key = (__float_as_uint(F) & ~31u) | (j * GRP + mth); // 5 position bits
-								q4 = umed3(q3, q4, key);
-								q3 = umed3(q2, q3, key);
-								q2 = umed3(q1, q2, key);
-								q1 = min(q1, key);
-							}
-						}
-					}
-					if (!rescan) {
-						auto seg_of = [&](uint32_t key) { // position in the scanned arrays -> chunk index
-							const uint32_t jj = (key & 31u) / GRP, mm = key & (GRP - 1);
-							const uint32_t pos = ((jj == 0 ? k1[p] : (jj == 1 ? k2[p] : k3[p])) & GMASK) * GRP + mm;
-							return use_list ? c_idx[CULL ? wv : 0][pos] : pos;
-						};
-						// q1 is the overall best filter value of a real segment (never a padded record)
-						exact_lds(p, seg_of(q1));
-						const bool s2 = !excluded(__uint_as_float(q2 & ~31u)), s3 = !excluded(__uint_as_float(q3 & ~31u));
-						const bool s4 = !excluded(__uint_as_float(q4 & ~31u));
-						if (q2 != 0xFFFFFFFFu && s2)
-							exact_lds(p, seg_of(q2));
-						if (q3 != 0xFFFFFFFFu && s3)
-							exact_lds(p, seg_of(q3));
-						if (q4 != 0xFFFFFFFFu && s4) {
-							exact_lds(p, seg_of(q4));
-							rescan = true; // four near-ties: more may hide behind them
-						}
-					}
-				}
-				if (rescan) {
-					// Rescan against a threshold Tk with L(Tk) > U (L increasing above it): fixed-point
-					// iteration for the crossing, pushed up, then VERIFIED; if the check fails nothing
-					// is excluded (Tk = inf).
-					float Tk = U + e64;
-					for (int it = 0; it < 3; it++)
-						Tk = U + e64 + filter_err(Tk * GSLACK, M);
-					Tk = Tk * 1.001f + 1e-30f;
-					if (!(Tk - filter_err(Tk * GSLACK, M) - e64 > U))
-						Tk = __builtin_inff();
-					for (uint32_t j = 0; j < ((ABL & 8) ? 0u : n_list); j++) {
-						const float F = sc_filter(rpx[p], rpy[p], a_vx[j], a_vy[j], a_dx[j], a_dy[j], a_inv[j]);
-						if (!(F > Tk))
-							exact_lds(p, use_list ? c_idx[CULL ? wv : 0][j] : j);
-					}
-				}
-			}
-		}
-	}
-
-#pragma unroll
-	for (int p = 0; p < PPL; p++) {
-		if (active[p]) {
-			// winding number = prefix sum of the row's histogram up to this column
-			int wn = 0;
-			const int *drow = s_delta + (row[p] - r_first) * stride;
-			for (uint32_t k = 0; k <= ((ABL & 16) ? 0u : x[p]); k++)
-				wn += drow[k];
-			out[g.out_off + o[p]] = quantise(best[p], wn != 0);
-		}
-	}
-}
-
-// ---------------------------------------------------------------------------------------
-// Variants 30 / 45 (third generation, 256-pixel tiles, kept for A/B): bounded groups — the reference's "ask the R-tree for the segments near this pixel"
-// (rtree_segments.rs:40-56) done the wave64 way.  Same staging, winding and exact evaluation as
-// above; what changes is which (pixel, segment) pairs the f32 filter looks at.
-//
-//   bound   every run of GRP = 8 consecutive segments of the chunk (neighbours on the outline,
-//           so a run is ~1 px long) gets an anchor a_g (the start vertex of its middle segment)
-//           and a radius r_g >= |q - a_g| for every point q of the run.
-//   phase 1 a lane evaluates D_g = |p - a_g| for the <= 32 groups of the chunk (4 VALU ops each,
-//           broadcast LDS reads), keeps U = min D_g (an upper bound of the true minimum: a_g is
-//           on the outline) and marks group g as a candidate iff D_g - r_g <= min(U, SAT): a
-//           32-bit mask per lane.  A segment of a non-candidate group is farther than the true
-//           minimum (triangle inequality), or farther than SAT = 6.2 px where the byte is
-//           saturated anyway (same argument as the per-wave cull).
-//   phase 2 the lane walks ITS OWN candidate groups (lane-divergent LDS reads; ~3.5 groups on
-//           Noto Sans instead of 60) with the scalar filter and the sorted top-4 of (F | index),
-//           then the exact evaluation / rescan exactly as in sdf_tiles_filtered.
-// All f32 roundings of phase 1 are covered by inflating U and r_g by (1 + 2^-9) and an absolute
-// pad of 0.01 + 1e-5 M px (anchor and record end points are within 8 u M < 2e-3 px of the true
-// ones for M < 4096; D_g^2 has relative error < 2^-21).  For M >= 4096 every group is a candidate.
-// ---------------------------------------------------------------------------------------
-template <int ABL, bool LAZY>
-__global__ __launch_bounds__(TPB) void sdf_tiles_hier(const GlyphDesc *__restrict__ glyphs,
-                                                      const uint2 *__restrict__ tiles, uint32_t n_tiles,
-                                                      const double *__restrict__ seg_sx,
-                                                      const double *__restrict__ seg_sy,
-                                                      const double *__restrict__ seg_ex,
-                                                      const double *__restrict__ seg_ey,
-                                                      uint8_t *__restrict__ out)
-{
-	constexpr uint32_t GRP = 8, NGRP = FCHUNK / GRP; // 32 groups per chunk: one mask bit each
-	static_assert(NGRP == 32 && TPB == FCHUNK, "one candidate bit per group, one staging thread per record");
-	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
-	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
-	__shared__ int s_delta[DELTA_CAP];
-	__shared__ uint32_t s_mbits;
-	__shared__ __attribute__((aligned(16))) float s_gx[NGRP], s_gy[NGRP], s_gr[NGRP]; // anchor, radius
-
-	const uint32_t tid = threadIdx.x;
-	const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-	const uint2 t = tiles[tile];
-	const GlyphDesc g = glyphs[t.x];
-	const uint32_t npix = g.w * g.h;
-	const double x0c = (double)g.x0 + 0.5, y0c = (double)g.y0 + 0.5;
-	const uint32_t o = t.y + tid;
-	const bool active = o < npix;
-	const uint32_t oc = active ? o : npix - 1;
-	const uint32_t row = oc / g.w;
-	const uint32_t x = oc - row * g.w;
-	const uint32_t y = g.h - 1 - row;
-	const double px = (double)x + x0c, py = (double)y + y0c; // renderer_precise.rs:27-28,34,62
-	const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
-
-	const uint32_t last_o = min(t.y + (uint32_t)TPB, npix) - 1;
-	const uint32_t r_first = t.y / g.w, r_last = last_o / g.w;
-	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
-	const uint32_t stride = g.w + 1;
-	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
-	for (uint32_t i = tid; i < n_delta; i += TPB)
-		s_delta[i] = 0;
-
-	const float wh = (float)max(g.w, g.h);
-	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
-	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
-	double best = __builtin_huge_val(); // rtree_segments.rs:57
-	float ub2 = __builtin_inff();       // squared distance to the nearest anchor / exact candidate so far
-	float qmin = 1.0e9f;                // LAZY: smallest decided distance bin floor(32 d + 0.5) over the chunks
-
-	auto exact_lds = [&](uint32_t i) {
-		const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
-		const double dx = wx - vx, dy = wy - vy; // segment.rs:63
-		const double d2 = exact_dist_sq(px, py, vx, vy, wx, wy, dx, dy, dx * dx + dy * dy);
-		best = d2 < best ? d2 : best; // rtree_segments.rs:60-62
-	};
-
-	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
-		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
-		__syncthreads(); // previous chunk fully consumed (and s_delta zeroed on the first trip)
-		if (tid == 0)
-			s_mbits = __float_as_uint(wh);
-		__syncthreads();
-
-		// ---- stage (thread i <-> record i): exact endpoints, f32 record, coordinate bound, crossings ----
-		{
-			const uint32_t i = tid;
-			float mf = 0.0f;
-			if (i >= cnt) { // pad the chunk with records that can never win (F = 2e36)
-				s_vx[i] = 1.0e18f;
-				s_vy[i] = 1.0e18f;
-				s_dx[i] = 0.0f;
-				s_dy[i] = 0.0f;
-				s_inv[i] = 0.0f;
-			} else {
-				const uint32_t s = g.seg_off + c0 + i;
-				const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
-				e_vx[i] = vx;
-				e_vy[i] = vy;
-				e_wx[i] = wx;
-				e_wy[i] = wy;
-				const double dx = wx - vx, dy = wy - vy;
-				const double l2 = dx * dx + dy * dy;
-				const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
-				const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
-				s_vx[i] = (float)rvx;
-				s_vy[i] = (float)rvy;
-				s_dx[i] = (float)dx;
-				s_dy[i] = (float)dy;
-				s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
-				const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
-				mf = (float)m * 1.000001f;               // round up
-				mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
-				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
-				if (!(ABL & 1) && vy != wy) {
-					const bool up = vy < wy;
-					const double lo = up ? vy : wy, hi = up ? wy : vy;
-					const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
-					const int yb = first_ge(hi, y0c, y_lo, y_hi + 1);
-					for (int yy = ya; yy < yb; yy++) {
-						const double pyy = (double)yy + y0c;
-						const double tc = (pyy - vy) / dy;
-						const double xc = vx + tc * dx;               // :45-46 / :48-49
-						const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
-						if (k < (int)g.w)
-							atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
-					}
-				}
-			}
-			// coordinate bound: wave maximum first, one LDS atomic per wave (non-negative floats order like uints)
-			uint32_t mb = __float_as_uint(mf);
-			for (int sh = 32; sh > 0; sh >>= 1)
-				mb = max(mb, (uint32_t)__shfl_xor((int)mb, sh));
-			if ((tid & 63) == 0)
-				atomicMax(&s_mbits, mb);
-		}
-		__syncthreads();
-		const float Mc = __uint_as_float(s_mbits);
-		const bool sane = Mc < 1.0e6f;   // else: no usable f32 bound -> every segment is evaluated exactly
-		const bool bounded = Mc < 4096.0f; // group bounds have a useful margin
-		const float pad = 0.01f + 1.0e-5f * Mc;
-		constexpr float INFL = 1.0f + 1.0f / 512.0f;
-		const uint32_t n_groups = (cnt + GRP - 1) / GRP;
-
-		// ---- group bounds: anchor = start vertex of the middle member, radius over all end points ----
-		{
-			const uint32_t gb = tid & ~(GRP - 1);
-			const uint32_t ai = min(gb + GRP / 2, cnt - 1);
-			const float ax = s_vx[ai], ay = s_vy[ai];
-			float r2 = 0.0f;
-			if (tid < cnt) {
-				const float vx = s_vx[tid], vy = s_vy[tid];
-				const float wx = vx + s_dx[tid], wy = vy + s_dy[tid];
-				const float ex = vx - ax, ey = vy - ay, fx = wx - ax, fy = wy - ay;
-				const float dv = __builtin_fmaf(ey, ey, ex * ex), dw = __builtin_fmaf(fy, fy, fx * fx);
-				r2 = dv > dw ? dv : dw;
-			}
-			for (int sh = 1; sh < (int)GRP; sh <<= 1) {
-				const float other = __shfl_xor(r2, sh);
-				r2 = other > r2 ? other : r2;
-			}
-			if ((tid & (GRP - 1)) == 0) {
-				const bool empty = gb >= cnt;
-				s_gx[tid / GRP] = empty ? 1.0e18f : ax;
-				s_gy[tid / GRP] = empty ? 1.0e18f : ay;
-				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL;
-			}
-		}
-		__syncthreads();
-
-		// ---- phase 1: candidate groups of this lane ----
-		uint32_t cand = n_groups >= 32 ? 0xFFFFFFFFu : ((1u << n_groups) - 1u);
-		if (bounded && !(ABL & 32)) {
-			float D2[NGRP];
-			uint32_t dmin = __float_as_uint(ub2);
-			const float4 *gx4 = reinterpret_cast<const float4 *>(s_gx), *gy4 = reinterpret_cast<const float4 *>(s_gy);
-			const float4 *gr4 = reinterpret_cast<const float4 *>(s_gr);
-#pragma unroll
-			for (uint32_t b = 0; b < NGRP / 4; b++) {
-				if (b * 4 < n_groups) {
-					const float4 ax = gx4[b], ay = gy4[b];
-					const float axs[4] = {ax.x, ax.y, ax.z, ax.w}, ays[4] = {ay.x, ay.y, ay.z, ay.w};
-#pragma unroll
-					for (int j = 0; j < 4; j++) {
-						const float ddx = rpx - axs[j], ddy = rpy - ays[j];
-						const float d2 = __builtin_fmaf(ddy, ddy, ddx * ddx);
-						D2[b * 4 + j] = d2;
-						dmin = min(dmin, __float_as_uint(d2)); // d2 >= +0: unsigned order is float order
-					}
-				} else {
-#pragma unroll
-					for (int j = 0; j < 4; j++)
-						D2[b * 4 + j] = __builtin_inff();
-				}
-			}
-			ub2 = __uint_as_float(dmin);
-			float U = (__builtin_sqrtf(ub2) * INFL + pad) * INFL;
-			U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
-			// One bit per group, 3 VALU ops each: tt = U + r_g, diff = tt^2 - D_g^2 (sign bit set <=> not
-			// a candidate; -inf for the groups past n_groups), shifted in with v_alignbit.  The bits
-			// arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
-			uint32_t rej = 0xFFFFFFFFu;
-#pragma unroll
-			for (uint32_t b = 0; b < NGRP / 4; b++) {
-				float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-				if (b * 4 < n_groups)
-					r = gr4[b];
-				const float rs[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-				for (int j = 0; j < 4; j++) {
-					const float tt = U + rs[j];
-					const float diff = __builtin_fmaf(tt, tt, -D2[b * 4 + j]);
-					rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(diff), 31); // (rej << 1) | sign(diff)
-				}
-			}
-			cand = __builtin_bitreverse32(~rej);
-		}
-
-		// ---- phase 2: f32 filter over the lane's candidate groups, sorted top-4 of (F | index) ----
-		uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
-		const float4 *q_vx = reinterpret_cast<const float4 *>(s_vx), *q_vy = reinterpret_cast<const float4 *>(s_vy);
-		const float4 *q_dx = reinterpret_cast<const float4 *>(s_dx), *q_dy = reinterpret_cast<const float4 *>(s_dy);
-		const float4 *q_inv = reinterpret_cast<const float4 *>(s_inv);
-		if (sane && !(ABL & 2)) {
-			uint32_t m = cand;
-			while (m) {
-				const uint32_t gq = (uint32_t)__builtin_ctz(m);
-				m &= m - 1;
-				const float4 vxa = q_vx[2 * gq], vya = q_vy[2 * gq], dxa = q_dx[2 * gq], dya = q_dy[2 * gq], iva = q_inv[2 * gq];
-				const float4 vxb = q_vx[2 * gq + 1], vyb = q_vy[2 * gq + 1], dxb = q_dx[2 * gq + 1], dyb = q_dy[2 * gq + 1],
-				             ivb = q_inv[2 * gq + 1];
-				const float vxs[8] = {vxa.x, vxa.y, vxa.z, vxa.w, vxb.x, vxb.y, vxb.z, vxb.w};
-				const float vys[8] = {vya.x, vya.y, vya.z, vya.w, vyb.x, vyb.y, vyb.z, vyb.w};
-				const float dxs[8] = {dxa.x, dxa.y, dxa.z, dxa.w, dxb.x, dxb.y, dxb.z, dxb.w};
-				const float dys[8] = {dya.x, dya.y, dya.z, dya.w, dyb.x, dyb.y, dyb.z, dyb.w};
-				const float ivs[8] = {iva.x, iva.y, iva.z, iva.w, ivb.x, ivb.y, ivb.z, ivb.w};
-				const uint32_t base = gq * GRP;
-				if (LAZY) {
-					// only the smallest filter value is tracked (F >= +0: unsigned order of the bits is float
-					// order): it decides the byte for ~99 % of the pixels; the rest rescans its candidates
-					uint32_t fb[GRP];
-#pragma unroll
-					for (uint32_t j = 0; j < GRP; j++)
-						fb[j] = __float_as_uint(sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]));
-					uint32_t mn;
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(k1), "v"(fb[0]), "v"(fb[1]));
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[2]), "v"(fb[3]));
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(fb[4]), "v"(fb[5]));
-					asm("v_min3_u32 %0, %1, %2, %3" : "=v"(k1) : "v"(mn), "v"(fb[6]), "v"(fb[7]));
-				} else {
-#pragma unroll
-					for (uint32_t j = 0; j < GRP; j++) {
-						const float F = sc_filter(rpx, rpy, vxs[j], vys[j], dxs[j], dys[j], ivs[j]);
-						const uint32_t key = (__float_as_uint(F) & ~IDX_MASK) | base | j;
-						k4 = umed3(k3, k4, key); // sorted quadruple: clamp(key, k_{j-1}, k_j)
-						k3 = umed3(k2, k3, key);
-						k2 = umed3(k1, k2, key);
-						k1 = min(k1, key);
-					}
-				}
-			}
-		}
-
-		if (!(ABL & 4)) {
-			if (!sane) {
-				for (uint32_t j = 0; j < cnt; j++)
-					exact_lds(j);
-			} else if (k1 != 0xFFFFFFFFu) {
-				const float M = Mc;
-				const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
-				// keys carry the index in their low bits (truncated value fk <= F <= fk SLACK); LAZY keeps F itself
-				const uint32_t val_mask = LAZY ? 0xFFFFFFFFu : ~IDX_MASK;
-				const float SLACK = LAZY ? 1.0f : KEY_SLACK;
-				const float f1 = __uint_as_float(k1 & val_mask) * SLACK;
-				float U = f1 + filter_err(f1, M) + e64;
-				if (!(U >= 0.0f))
-					U = __builtin_inff();
-				auto excluded = [&](uint32_t key) {
-					const float fk = __uint_as_float(key & val_mask);
-					return fk - filter_err(fk * SLACK, M) - e64 > U; // false for NaN / inf U
-				};
-				auto real = [&](uint32_t key) { return key != 0xFFFFFFFFu && (key & IDX_MASK) < cnt; };
-				// rescan of the lane's candidate groups against a key threshold Tk with L(Tk) > U (L increasing
-				// above it): fixed-point iteration for the crossing, pushed up, then VERIFIED; if the check
-				// fails nothing is excluded (Tk = inf)
-				auto rescan = [&]() {
-					float Tk = U + e64;
-					for (int it = 0; it < 3; it++)
-						Tk = U + e64 + filter_err(Tk * SLACK, M);
-					Tk = Tk * 1.001f + 1e-30f;
-					if (!(Tk - filter_err(Tk * SLACK, M) - e64 > U))
-						Tk = __builtin_inff();
-					uint32_t m = cand;
-					while (m) {
-						const uint32_t gq = (uint32_t)__builtin_ctz(m);
-						m &= m - 1;
-						const uint32_t je = gq * GRP + GRP < cnt ? gq * GRP + GRP : cnt;
-						for (uint32_t j = gq * GRP; j < je; j++) {
-							const float F = sc_filter(rpx, rpy, s_vx[j], s_vy[j], s_dx[j], s_dy[j], s_inv[j]);
-							const float fk = __uint_as_float(__float_as_uint(F) & val_mask);
-							if (!(fk > Tk))
-								exact_lds(j);
-						}
-					}
-				};
-				if (LAZY) {
-					// The chunk's minimum C lies in [LB, U] (every candidate's F is >= the smallest one, L is
-					// increasing for f >= c^2, c = 1.001 * 64 u M; segments of non-candidate groups are beyond
-					// the true minimum or beyond SAT, 6.16^2 = 38).  Both bytes are functions of the bin
-					// q = floor(32 sqrt(C) + 1/2) (renderer_precise.rs:71-79: 191 - q outside, 191 + q inside);
-					// if the whole interval falls into one bin no f64 work is needed for this chunk.  The
-					// reference's own roundings move 32 sqrt(C) by < 1e-12, the f32 evaluation by < 1e-4.
-					bool decided = false;
-					if (U < 1.0e30f) {
-						const float fk = __uint_as_float(k1);
-						const float cc = 3.83e-6f * M;
-						float LB = fk > cc * cc ? fk - filter_err(fk, M) - e64 : 0.0f;
-						LB = LB > 0.0f ? LB : 0.0f;
-						LB = LB < 38.0f ? LB : 38.0f;
-						const float Uc = U < 38.0f ? U : 38.0f;
-						const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 1.0e-3f));
-						const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 1.0e-3f));
-						if (q_lo == q_hi) {
-							qmin = q_lo < qmin ? q_lo : qmin;
-							decided = true;
-						}
-					}
-					if (decided) {
-						const float uf = U * (1.0f + 1.0f / 1048576.0f);
-						ub2 = uf < ub2 ? uf : ub2;
-					} else {
-						rescan(); // every candidate that cannot be excluded is evaluated exactly
-					}
-				} else {
-					// ---- exact evaluation of the candidates that cannot be excluded (as in sdf_tiles_filtered) ----
-					if (real(k1))
-						exact_lds(k1 & IDX_MASK);
-					if (real(k2) && !excluded(k2))
-						exact_lds(k2 & IDX_MASK);
-					if (real(k3) && !excluded(k3))
-						exact_lds(k3 & IDX_MASK);
-					if (k4 != 0xFFFFFFFFu && !excluded(k4)) {
-						if (real(k4))
-							exact_lds(k4 & IDX_MASK);
-						rescan(); // four near-ties: more may hide behind them
-					}
-				}
-			}
-			// the exact minimum so far bounds the later chunks too
-			const float bf = (float)best * (1.0f + 1.0f / 1048576.0f);
-			ub2 = bf < ub2 ? bf : ub2;
-		}
-	}
-
-	if (active) {
-		// winding number = prefix sum of the row's histogram up to this column
-		int wn = 0;
-		const int *drow = s_delta + (row - r_first) * stride;
-		for (uint32_t k = 0; k <= x; k++)
-			wn += drow[k];
-		uint8_t byte = quantise(best, wn != 0); // +inf (nothing evaluated exactly) -> 0 outside, 255 inside
-		if (LAZY && qmin < 1.0e8f) {
-			// the nearest segment gives the largest byte outside, the smallest inside
-			const int q = (int)qmin;
-			const int bq = wn != 0 ? min(191 + q, 255) : max(191 - q, 0);
-			byte = wn != 0 ? (uint8_t)min((int)byte, bq) : (uint8_t)max((int)byte, bq);
-		}
-		out[g.out_off + o] = byte;
-	}
-}
+#ifdef VGSDF_DEV_VARIANTS
+} // namespace vgsdf
+#include "dev/sdf_retired.inc" // earlier kernel generations (A/B measurements, development builds only)
+namespace vgsdf {
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Chunk boxes (batch preparation, run once per resident batch): the bounding box of every chunk
@@ -1750,8 +710,20 @@ extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t
 	return (int)hipGetLastError();
 }
 
-// variant ids: see vgsdf_batch_launch (vgsdf_device.cpp).  1 = brute force, also the fallback for the
-// tiles the host routes there: glyphs too wide for the winding histogram, or with >= 2^24 segments.
+// kernel ids: 50 = the bounded-group span kernel (public variant 0), 1 = brute force, also the fallback
+// for the tiles the host routes there: glyphs too wide for the winding histogram, or with >= 2^24
+// segments.  Everything else exists only in development builds (-DVGSDF_DEV_VARIANTS).
+extern "C" int vgsdf_kernel_known(int kernel)
+{
+#ifdef VGSDF_DEV_VARIANTS
+	switch (kernel) {
+	case 10: case 12: case 22: case 23: case 30: case 45: case 51: case 52: case 53: case 54: case 55: case 56: case 57:
+		return 1;
+	}
+#endif
+	return kernel == 1 || kernel == 50;
+}
+
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
                                   const uint2 *tiles, uint32_t n_tiles_in, const double *sx,
                                   const double *sy, const double *ex, const double *ey, uint8_t *out,
@@ -1762,25 +734,25 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const dim3 grid(n_tiles_in);
 	// kernel argument: tile count, top bit set = dispatch in list order (no per-XCD remap)
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
+#define VG_LAUNCH_SPAN(A)                                                                                 \
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
+	                   sx, sy, ex, ey, out, (const float4 *)boxes)
+	if (variant == 1)
+		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
+		                   tiles, n_tiles, sx, sy, ex, ey, out);
+	else if (variant == 50) // bounded groups over spans of up to 4 tiles (tile list: first pixel | T)
+		VG_LAUNCH_SPAN(0);
+#ifdef VGSDF_DEV_VARIANTS
+	// development builds only (`make dev`): timing-only ablations (WRONG pixels) and earlier generations
 #define VG_LAUNCH_PK(A, C, P)                                                                            \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C, P>), grid, dim3(vgsdf::TPB / P), 0, stream, glyphs, tiles,  \
 	                   n_tiles, sx, sy, ex, ey, out)
 #define VG_LAUNCH_HIER(A, L)                                                                               \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_hier<A, L>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
 	                   sx, sy, ex, ey, out)
-#define VG_LAUNCH_SPAN(A)                                                                                 \
-	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
-	                   sx, sy, ex, ey, out, (const float4 *)boxes)
 #define VG_LAUNCH_FILTERED(A, C)                                                                          \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_filtered<A, C>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, \
 	                   tiles, n_tiles, sx, sy, ex, ey, out)
-	if (variant == 1)
-		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
-		                   tiles, n_tiles, sx, sy, ex, ey, out);
-	else if (variant == 30) // bounded groups
-		VG_LAUNCH_HIER(0, false);
-	else if (variant == 50) // bounded groups over spans of up to 4 tiles (tile list: first pixel | T)
-		VG_LAUNCH_SPAN(0);
 	else if (variant == 51) // timing-only ablations of the span kernel: no phase 2 (and nothing after it)
 		VG_LAUNCH_SPAN(2);
 	else if (variant == 52) // ... no exact fallback
@@ -1795,26 +767,19 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_SPAN(64);
 	else if (variant == 57) // A/B: no chunk-box skipping
 		VG_LAUNCH_SPAN(128);
-	else if (variant == 45) // bounded groups, exact evaluation only where the byte is undecided
+	else if (variant == 30) // bounded groups on 256-pixel tiles
+		VG_LAUNCH_HIER(0, false);
+	else if (variant == 45) // ... exact evaluation only where the byte is undecided
 		VG_LAUNCH_HIER(0, true);
-	else if (variant == 31) // timing-only: no phase 2
-		VG_LAUNCH_HIER(2, false);
-	else if (variant == 32) // timing-only: no phase 2, no exact
-		VG_LAUNCH_HIER(6, false);
-	else if (variant == 33) // timing-only: staging only (no winding, phases, exact)
-		VG_LAUNCH_HIER(39, false);
-	else if (variant == 34) // timing-only: no winding
-		VG_LAUNCH_HIER(1, false);
-	else if (variant == 35) // timing-only: no exact evaluation
-		VG_LAUNCH_HIER(4, false);
-	else if (variant == 22) // earlier generation: packed filter, grouped selection (A/B)
+	else if (variant == 22) // packed filter, grouped selection
 		VG_LAUNCH_PK(0, false, 1);
 	else if (variant == 23) // ... with per-wave culling
 		VG_LAUNCH_PK(0, true, 1);
-	else if (variant == 12) // earlier generation: scalar filter, top-4 keys (A/B)
+	else if (variant == 12) // scalar filter, top-4 keys
 		VG_LAUNCH_FILTERED(0, false);
 	else if (variant == 10) // ... with per-wave culling
 		VG_LAUNCH_FILTERED(0, true);
+#endif
 	else
 		return (int)hipErrorInvalidValue;
 	return (int)hipGetLastError();

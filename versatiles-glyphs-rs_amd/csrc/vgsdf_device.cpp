@@ -24,16 +24,20 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // true when p is page-locked host memory known to HIP (hipHostMalloc / vgsdf_host_alloc):
 // such arrays are DMA'd straight from/to the caller without a staging copy
-inline bool is_pinned(const void *p)
+inline bool is_pinned(const void *p, size_t bytes)
 {
 	if (!p)
 		return false;
-	hipPointerAttribute_t a;
-	if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-		(void)hipGetLastError(); // plain malloc memory: clear the sticky error
-		return false;
+	for (const void *q : {p, (const void *)((const uint8_t *)p + (bytes ? bytes - 1 : 0))}) { // first and last byte
+		hipPointerAttribute_t a;
+		if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+			(void)hipGetLastError(); // plain malloc memory: clear the sticky error
+			return false;
+		}
+		if (a.type != hipMemoryTypeHost)
+			return false;
 	}
-	return a.type == hipMemoryTypeHost;
+	return true;
 }
 
 } // namespace
@@ -208,6 +212,12 @@ int vgsdf_set_variant(vgsdf_ctx *ctx, int variant)
 {
 	if (!ctx)
 		return VGSDF_E_ARG;
+	// the product build knows 0 (default) and 1 (brute force); development builds (-DVGSDF_DEV_VARIANTS)
+	// add the earlier generations and the timing-only ablations
+	if (!vgsdf_kernel_known(variant == 0 ? 50 : (variant == 13 ? 10 : variant)) || variant == 50) {
+		ctx->err = "vgsdf_set_variant: unknown kernel variant " + std::to_string(variant);
+		return VGSDF_E_ARG;
+	}
 	ctx->variant = variant;
 	return VGSDF_OK;
 }
@@ -342,11 +352,11 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 		tl_sort += ts1 - ts0;
 		// entries of glyph g: one per span of T tiles (T = 1 unless this is the span list's main class)
 		auto emit = [&](uint32_t g, auto &&push) {
-			const uint32_t px = in->w[g] * in->h[g];
+			const uint64_t px = (uint64_t)in->w[g] * in->h[g]; // <= 2^32 - 1 - 256 (validated by the callers)
 			const uint32_t T = span_t[g];
-			for (uint32_t p = 0; p < px; p += VGSDF_TILE_PIXELS * T) {
-				const uint32_t left = (px - p + VGSDF_TILE_PIXELS - 1) >> 8;
-				push(make_uint2(g, span && cls == 0 ? (p | std::min(T, left)) : p));
+			for (uint64_t p = 0; p < px; p += (uint64_t)VGSDF_TILE_PIXELS * T) { // 64-bit: p + 1024 may pass 2^32
+				const uint32_t left = (uint32_t)((px - p + VGSDF_TILE_PIXELS - 1) >> 8);
+				push(make_uint2(g, span && cls == 0 ? ((uint32_t)p | std::min(T, left)) : (uint32_t)p));
 			}
 		};
 		uint64_t n_cls_tiles = 0;
@@ -489,8 +499,9 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	(void)hipSetDevice(ctx->device);
 	hipError_t e = hipSuccess;
 	// segment arrays already page-locked: DMA them directly, stage only descriptors + tiles
-	const bool direct = n_seg && is_pinned(in->seg_sx) && is_pinned(in->seg_sy) && is_pinned(in->seg_ex) &&
-	                    is_pinned(in->seg_ey);
+	const size_t seg_nb = sizeof(double) * (size_t)n_seg;
+	const bool direct = n_seg && is_pinned(in->seg_sx, seg_nb) && is_pinned(in->seg_sy, seg_nb) &&
+	                    is_pinned(in->seg_ex, seg_nb) && is_pinned(in->seg_ey, seg_nb);
 	const size_t stage_bytes = direct ? off_sx : b->input_bytes;
 	if (use_ctx_scratch) {
 		b->borrowed = true;
@@ -573,6 +584,10 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 		}
 		if (e == hipSuccess && b->span_list)
 			e = (hipError_t)vgsdf_launch_chunk_boxes(b->d_glyphs, n, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_boxes, ctx->stream);
+		// page-locked caller arrays are DMA'd in place: the copies must be over before the caller may
+		// touch them again (vgsdf.h: the batch is read-only "for the call")
+		if (e == hipSuccess && direct)
+			e = hipStreamSynchronize(ctx->stream);
 		if (e != hipSuccess) {
 			ctx->err = std::string("vgsdf_batch_upload: H2D: ") + hipGetErrorString(e);
 			vgsdf_batch_free(ctx, b);
@@ -613,11 +628,9 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 		return VGSDF_E_ARG;
 	}
 	(void)hipSetDevice(ctx->device);
-	// variant 0 (default) = 50: bounded groups over spans of tiles; misfits: brute force.
-	// 1: everything brute.  Earlier generations kept for A/B (all bit-exact): 45 bounded groups on
-	// 256-pixel tiles, 30 ... with the exact evaluation in every chunk, 22 / 23 packed grouped filter
-	// without / with per-wave culling, 12 / 13 scalar top-4 filter without / with culling.
-	// 31-35 / 51-55: timing-only ablations of 30 / 50 (wrong pixels).
+	// variant 0 (default) = kernel 50: bounded groups over spans of tiles; misfits: brute force.
+	// 1: everything brute.  Other ids exist only in development builds (vgsdf_set_variant rejects them
+	// otherwise): earlier generations and timing-only ablations, see vgsdf_launch_tiles.
 	const uint32_t n_all = (uint32_t)b->stats.n_tiles;
 	const int v = ctx->variant;
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
