@@ -3,6 +3,10 @@
  * FontManager / GlyphBlock / Renderer with the reference's names and semantics, driving
  * the GPU raster of vgsdf.h.  Replaces, for the render path only:
  *   FontManager::{new,add_font_with_name,render_glyphs}  /root/reference/src/font/manager.rs:28,66,81
+ *   FontManager::{add_path,add_paths}, scan              manager.rs:39-61, src/commands/recurse.rs:104-133
+ *   write_index_json / write_families_json               manager.rs:128-138, src/font/index_files.rs:65-143
+ *   Writer::{new_tar,new_file}                           src/writer/mod.rs:27-41, tar.rs:30-157, file.rs:10-52
+ *   parse_font_name / FontMetadata::generate_name        src/font/parse_font_name.rs:214-291, metadata.rs:43-68
  *   GlyphBlock::render                                   src/font/glyph_block.rs:69
  *   Renderer::{new,new_precise,new_dummy,render_glyph}   src/render/renderer.rs:25-43,103
  * This header exists so tests/bench (Python ctypes) and non-C++ callers can reach the
@@ -61,13 +65,50 @@ void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per
 void vg_manager_set_device_front_end(vg_manager *m, int on);
 int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
 int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
-int vg_manager_add_path(vg_manager *m, const char *path); /* always fails: out of scope, see header */
+/* manager.rs:39-53: the file's name table decides the font id (family/width/weight/style ->
+ * generate_name -> name_to_id); files with the same id merge in call order. */
+int vg_manager_add_path(vg_manager *m, const char *path);
+/* recurse.rs:104-133 `scan`: *.ttf / *.otf files are added by add_path; a directory holding a
+ * fonts.json ([{name, sources[]}], paths relative to it) is read through that file; other
+ * directories are walked, entries in ascending byte order of their names (canonical order). */
+int vg_manager_scan(vg_manager *m, const char *path);
+/* font ids (ascending), '\n' separated, NUL terminated; returns the needed size incl. NUL */
+long vg_manager_font_ids(const vg_manager *m, char *out, size_t cap);
+/* raw family names (name id 1) of the files of one font id in wrapper order, '\n' separated */
+long vg_manager_font_file_names(const vg_manager *m, const char *font_id, char *out, size_t cap);
+/* parse_font_name(family, ps_name): style_out / width_out need 16 bytes each; returns the
+ * length of the family (written NUL terminated into family_out, truncated to cap). */
+int vg_parse_font_name(const char *family, const char *ps_name, char *family_out, size_t cap, char *style_out,
+                       uint16_t *weight_out, char *width_out);
+/* FontMetadata::generate_name of file `file_index` of a font id -> out; returns the needed size */
+long vg_manager_generate_name(const vg_manager *m, const char *font_id, int file_index, char *out, size_t cap);
+/* encode_codeblocks (index_files.rs:65-103); returns the needed size incl. NUL */
+long vg_encode_codeblocks(const uint32_t *codepoints, size_t n, char *out, size_t cap);
+/* build_index_json / build_font_families_json: returns the needed size (no NUL) */
+long vg_manager_index_json(const vg_manager *m, uint8_t *out, size_t cap);
+long vg_manager_families_json(const vg_manager *m, uint8_t *out, size_t cap);
 /* name_to_id (manager.rs:141-147); writes a NUL-terminated id, returns its length */
 int vg_name_to_id(const char *name, char *out, size_t cap);
 /* number of code points (<= 0xFFFF) the font id maps after first-provider-wins merging */
 int vg_manager_block_counts(const vg_manager *m, const char *font_id, uint32_t counts[256]);
 
+/* Native sinks (src/writer): a ustar stream into a file or an open descriptor (e.g. 1 = stdout,
+ * `recurse --tar`), or a directory tree.  mtime < 0 stamps every tar header with the wall clock as
+ * the reference does (tar.rs:68-72); tests pass a fixed time to get reproducible bytes. */
+typedef struct vg_writer vg_writer;
+vg_writer *vg_writer_new_tar_path(const char *path, int64_t mtime);
+vg_writer *vg_writer_new_tar_fd(int fd, int64_t mtime); /* the descriptor is NOT closed */
+vg_writer *vg_writer_new_dir(const char *folder);
+int vg_writer_write_file(vg_writer *w, const char *path, const uint8_t *data, size_t len);
+int vg_writer_write_directory(vg_writer *w, const char *path);
+int vg_writer_finish(vg_writer *w); /* idempotent (writer/mod.rs:71-77) */
+void vg_writer_free(vg_writer *w);  /* finishes first, like Drop (mod.rs:84-96) */
+
 int vg_manager_render_glyphs(vg_manager *m, vg_renderer *r, vg_write_cb cb, void *user);
+/* the same into a native sink; index.json / font_families.json as manager.rs:128-138 */
+int vg_manager_render_glyphs_to(vg_manager *m, vg_renderer *r, vg_writer *w);
+int vg_manager_write_index_json(const vg_manager *m, vg_writer *w);
+int vg_manager_write_families_json(const vg_manager *m, vg_writer *w);
 /* A rank's shard: only the listed block starts (multiples of 256) of one font id. */
 int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id, const uint32_t *starts, int n,
                              vg_write_cb cb, void *user);

@@ -12,6 +12,7 @@ from .device import (  # noqa: F401
     Batch, DeviceBatch, OUTLINE_CMD_DTYPE, RECT_DTYPE, SdfContext, VgsdfError, device_count, make_batch, load_library,
 )
 from .host import (  # noqa: F401
-    DummyWriter, FontManager, GlyphBatchHost, PbfGlyph, Renderer, name_to_id, pbf_encode,
+    DummyWriter, FontManager, GlyphBatchHost, NativeWriter, PbfGlyph, Renderer, encode_codeblocks, name_to_id, parse_font_name,
+    pbf_encode,
 )
 from .dispatch import render_sharded, shard_blocks  # noqa: F401

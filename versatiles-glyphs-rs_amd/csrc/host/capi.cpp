@@ -2,8 +2,12 @@
 #include <cstring>
 #include <stdexcept>
 
+#include <unistd.h>
+
 #include "../../../include/vgfont.h"
 #include "font_manager.hpp"
+#include "index_files.hpp"
+#include "writers.hpp"
 
 namespace {
 thread_local std::string g_err;
@@ -20,6 +24,9 @@ struct vg_renderer {
 struct vg_manager {
 	vg::FontManager m;
 	explicit vg_manager(bool p) : m(p) {}
+};
+struct vg_writer {
+	std::unique_ptr<vg::Writer> w;
 };
 struct vg_outline_batch {
 	vg::OutlineBatch b;
@@ -91,6 +98,178 @@ int vg_manager_add_path(vg_manager *m, const char *path)
 	std::string err;
 	return m->m.add_path(path, &err) ? 0 : fail(err);
 }
+int vg_manager_scan(vg_manager *m, const char *path)
+{
+	std::string err;
+	return m->m.scan(path, &err) ? 0 : fail(err);
+}
+
+static long copy_out(const std::string &s, char *out, size_t cap, bool nul)
+{
+	if (out && cap) {
+		const size_t n = std::min(nul ? cap - 1 : cap, s.size());
+		std::memcpy(out, s.data(), n);
+		if (nul)
+			out[n] = 0;
+	}
+	return (long)(s.size() + (nul ? 1 : 0));
+}
+
+long vg_manager_font_ids(const vg_manager *m, char *out, size_t cap)
+{
+	std::string s;
+	for (const auto &kv : m->m.fonts()) {
+		if (!s.empty())
+			s.push_back('\n');
+		s += kv.first;
+	}
+	return copy_out(s, out, cap, true);
+}
+
+long vg_manager_font_file_names(const vg_manager *m, const char *font_id, char *out, size_t cap)
+{
+	auto it = m->m.fonts().find(font_id);
+	if (it == m->m.fonts().end())
+		return fail(std::string("unknown font id ") + font_id);
+	std::string s;
+	for (const auto &f : it->second.files()) {
+		if (!s.empty())
+			s.push_back('\n');
+		s += f->metadata().name;
+	}
+	return copy_out(s, out, cap, true);
+}
+
+int vg_parse_font_name(const char *family, const char *ps_name, char *family_out, size_t cap, char *style_out,
+                       uint16_t *weight_out, char *width_out)
+{
+	const vg::ParsedFontName p = vg::parse_font_name(family ? family : "", ps_name ? ps_name : "");
+	copy_out(p.family, family_out, cap, true);
+	if (style_out)
+		copy_out(p.style, style_out, 16, true);
+	if (width_out)
+		copy_out(p.width, width_out, 16, true);
+	if (weight_out)
+		*weight_out = p.weight;
+	return (int)p.family.size();
+}
+
+long vg_manager_generate_name(const vg_manager *m, const char *font_id, int file_index, char *out, size_t cap)
+{
+	auto it = m->m.fonts().find(font_id);
+	if (it == m->m.fonts().end() || file_index < 0 || (size_t)file_index >= it->second.files().size())
+		return fail("unknown font id / file index");
+	return copy_out(it->second.files()[(size_t)file_index]->metadata().generate_name(), out, cap, true);
+}
+
+long vg_encode_codeblocks(const uint32_t *codepoints, size_t n, char *out, size_t cap)
+{
+	return copy_out(vg::encode_codeblocks(std::vector<uint32_t>(codepoints, codepoints + n)), out, cap, true);
+}
+
+long vg_manager_index_json(const vg_manager *m, uint8_t *out, size_t cap)
+{
+	const auto v = vg::build_index_json(m->m);
+	return copy_out(std::string(v.begin(), v.end()), (char *)out, cap, false);
+}
+
+long vg_manager_families_json(const vg_manager *m, uint8_t *out, size_t cap)
+{
+	try {
+		const auto v = vg::build_font_families_json(m->m);
+		return copy_out(std::string(v.begin(), v.end()), (char *)out, cap, false);
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+vg_writer *vg_writer_new_tar_path(const char *path, int64_t mtime)
+{
+	std::FILE *f = std::fopen(path, "wb");
+	if (!f) {
+		g_err = std::string("cannot create ") + path;
+		return nullptr;
+	}
+	return new vg_writer{std::unique_ptr<vg::Writer>(new vg::TarWriter(f, true, mtime))};
+}
+
+vg_writer *vg_writer_new_tar_fd(int fd, int64_t mtime)
+{
+	const int dupfd = ::dup(fd); // fclose() of our stream must not close the caller's descriptor
+	std::FILE *f = dupfd >= 0 ? ::fdopen(dupfd, "wb") : nullptr;
+	if (!f) {
+		if (dupfd >= 0)
+			::close(dupfd);
+		g_err = "cannot open descriptor " + std::to_string(fd) + " for writing";
+		return nullptr;
+	}
+	return new vg_writer{std::unique_ptr<vg::Writer>(new vg::TarWriter(f, true, mtime))};
+}
+
+vg_writer *vg_writer_new_dir(const char *folder) { return new vg_writer{std::unique_ptr<vg::Writer>(new vg::FileWriter(folder))}; }
+
+int vg_writer_write_file(vg_writer *w, const char *path, const uint8_t *data, size_t len)
+{
+	try {
+		w->w->write_file(path, std::vector<uint8_t>(data, data + len));
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+int vg_writer_write_directory(vg_writer *w, const char *path)
+{
+	try {
+		w->w->write_directory(path);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+int vg_writer_finish(vg_writer *w)
+{
+	try {
+		w->w->finish();
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+void vg_writer_free(vg_writer *w) { delete w; }
+
+int vg_manager_render_glyphs_to(vg_manager *m, vg_renderer *r, vg_writer *w)
+{
+	try {
+		m->m.render_glyphs(*w->w, *r->r);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+int vg_manager_write_index_json(const vg_manager *m, vg_writer *w)
+{
+	try {
+		m->m.write_index_json(*w->w);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
+int vg_manager_write_families_json(const vg_manager *m, vg_writer *w)
+{
+	try {
+		m->m.write_families_json(*w->w);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
 int vg_name_to_id(const char *name, char *out, size_t cap)
 {
 	const std::string id = vg::name_to_id(name);

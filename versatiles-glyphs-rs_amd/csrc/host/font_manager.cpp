@@ -1,6 +1,11 @@
 #include "font_manager.hpp"
 
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstring>
 #include <cstdio>
@@ -8,6 +13,8 @@
 #include <fstream>
 #include <stdexcept>
 #include <thread>
+
+#include "index_files.hpp"
 
 namespace vg {
 
@@ -85,6 +92,19 @@ std::unique_ptr<FontFileEntry> FontFileEntry::create(std::vector<uint8_t> data, 
 		return nullptr;
 	}
 	e->codepoints_ = e->face_.unicode_codepoints();
+	{
+		// metadata.rs:92-103: HashMap::from_iter over the name records — a later record of the same id
+		// replaces an earlier one, and a record ttf-parser cannot decode counts as an empty string
+		std::map<uint16_t, std::string> names;
+		for (auto &kv : e->face_.names())
+			names[kv.first] = std::move(kv.second);
+		e->metadata_.name = names.count(1) ? names[1] : std::string(); // name_id::FAMILY
+		const ParsedFontName pn = parse_font_name(e->metadata_.name, names.count(6) ? names[6] : std::string()); // POST_SCRIPT_NAME
+		e->metadata_.family = pn.family;
+		e->metadata_.style = pn.style;
+		e->metadata_.weight = pn.weight;
+		e->metadata_.width = pn.width;
+	}
 	return e;
 }
 
@@ -161,12 +181,89 @@ bool FontManager::add_font_data(const std::string &name, std::vector<uint8_t> da
 	return true;
 }
 
-bool FontManager::add_path(const std::string &, std::string *err)
+bool FontManager::add_path(const std::string &path, std::string *err)
 {
-	if (err)
-		*err = "add_path needs font family-name parsing (parse_font_name.rs), which is outside the "
-		       "accelerated path; use add_font_with_name(name, sources)";
-	return false;
+	std::vector<uint8_t> data;
+	if (!read_file(path, data, err))
+		return false;
+	auto e = FontFileEntry::create(std::move(data), err);
+	if (!e)
+		return false;
+	fonts_[name_to_id(e->metadata().generate_name())].add_file(std::move(e));
+	return true;
+}
+
+bool FontManager::add_paths(const std::vector<std::string> &paths, std::string *err)
+{
+	for (const std::string &p : paths)
+		if (!add_path(p, err))
+			return false;
+	return true;
+}
+
+bool FontManager::scan(const std::string &path, std::string *err)
+{
+	struct stat st;
+	if (::stat(path.c_str(), &st) != 0) // is_file() / is_dir() are both false: nothing to do (recurse.rs:105-111)
+		return true;
+	if (S_ISREG(st.st_mode)) {
+		// Path::extension(): what follows the last '.' of the file name (none for ".ttf" itself)
+		const size_t slash = path.find_last_of('/');
+		const std::string fname = slash == std::string::npos ? path : path.substr(slash + 1);
+		const size_t dot = fname.find_last_of('.');
+		const std::string ext = (dot == std::string::npos || dot == 0) ? std::string() : fname.substr(dot + 1);
+		if (ext == "ttf" || ext == "otf")
+			return add_path(path, err);
+		return true;
+	}
+	if (!S_ISDIR(st.st_mode))
+		return true;
+	const std::string base = (!path.empty() && path.back() == '/') ? path : path + "/";
+	const std::string cfg = base + "fonts.json";
+	if (::stat(cfg.c_str(), &st) == 0) {
+		std::vector<uint8_t> data;
+		if (!read_file(cfg, data, err)) {
+			if (err)
+				*err = "Failed to read \"" + cfg + "\": " + *err;
+			return false;
+		}
+		std::vector<FontConfig> configs;
+		if (!parse_fonts_json(std::string(data.begin(), data.end()), configs, err))
+			return false;
+		for (const FontConfig &c : configs) {
+			std::vector<std::string> sources;
+			for (const std::string &src : c.sources)
+				sources.push_back((!src.empty() && src[0] == '/') ? src : base + src); // Path::join
+			if (!add_font_with_name(c.name, sources, err))
+				return false;
+		}
+		return true;
+	}
+	DIR *d = ::opendir(path.c_str());
+	if (!d) {
+		if (err)
+			*err = "reading directory \"" + path + "\": " + std::strerror(errno);
+		return false;
+	}
+	std::vector<std::string> names;
+	while (struct dirent *ent = ::readdir(d)) {
+		const std::string n = ent->d_name;
+		if (n != "." && n != "..")
+			names.push_back(n);
+	}
+	::closedir(d);
+	std::sort(names.begin(), names.end());
+	for (const std::string &n : names)
+		if (!scan(base + n, err))
+			return false;
+	return true;
+}
+
+void FontManager::write_index_json(Writer &writer) const { writer.write_file("index.json", build_index_json(*this)); }
+
+void FontManager::write_families_json(Writer &writer) const
+{
+	writer.write_file("font_families.json", build_font_families_json(*this));
 }
 
 unsigned FontManager::worker_count() const

@@ -8,7 +8,8 @@
 //   name_to_id                          manager.rs:141-147
 //   WriterTrait                         src/writer/mod.rs:10-19
 //
-// Out of scope: family-name parsing (add_path), index/families JSON, tar.
+//   FontManager::{add_path,add_paths}  manager.rs:39-61;  scan  src/commands/recurse.rs:104-133
+//   write_index_json / write_families_json   manager.rs:128-138 (index_files.hpp)
 #pragma once
 #include <array>
 #include <cstdint>
@@ -18,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "font_name.hpp"
 #include "renderer.hpp"
 #include "thread_pool.hpp"
 
@@ -31,6 +33,7 @@ struct Writer {
 	virtual ~Writer() = default;
 	virtual void write_directory(const std::string &path) = 0;
 	virtual void write_file(const std::string &path, const std::vector<uint8_t> &data) = 0;
+	virtual void finish() {} // writer/mod.rs:71-77
 };
 
 // file_entry.rs: owns the bytes, the parsed face and the cmap coverage
@@ -39,11 +42,13 @@ public:
 	static std::unique_ptr<FontFileEntry> create(std::vector<uint8_t> data, std::string *err);
 	const Face &face() const { return face_; }
 	const std::vector<uint32_t> &codepoints() const { return codepoints_; } // metadata.rs:105-119
+	const FontMetadata &metadata() const { return metadata_; }                // metadata.rs:89-103
 
 private:
 	std::vector<uint8_t> data_;
 	Face face_;
 	std::vector<uint32_t> codepoints_;
+	FontMetadata metadata_;
 };
 
 // glyph_block.rs:10-16 — which file renders each of the 256 code points of a range
@@ -112,8 +117,19 @@ public:
 	// manager.rs:66-75
 	bool add_font_with_name(const std::string &name, const std::vector<std::string> &sources, std::string *err);
 	bool add_font_data(const std::string &name, std::vector<uint8_t> data, std::string *err);
-	// manager.rs:39-53 needs family-name parsing (parse_font_name.rs), which is out of scope
+	// manager.rs:39-53: the file's own name table decides the font id (family + width + weight + style
+	// through parse_font_name / generate_name / name_to_id); files with the same id merge, in call order
 	bool add_path(const std::string &path, std::string *err);
+	bool add_paths(const std::vector<std::string> &paths, std::string *err); // manager.rs:56-61
+	// recurse.rs:104-133: a file named *.ttf / *.otf is added; a directory with a fonts.json is read
+	// through it ([{name, sources[]}], sources relative to that directory) and NOT descended into; any
+	// other directory is walked.  The reference walks in fs::read_dir order (unspecified, so the
+	// first-provider-wins merge depends on the file system); here entries are visited in ascending
+	// byte order of their names, the canonical order of SURVEY.md §8a.
+	bool scan(const std::string &path, std::string *err);
+	// manager.rs:128-138
+	void write_index_json(Writer &writer) const;
+	void write_families_json(Writer &writer) const;
 
 	// manager.rs:81-125.  Host threads tessellate blocks into SoA batches, the GPU renders
 	// them, blocks are PBF-encoded and handed to the writer in task order.  Throws

@@ -52,6 +52,7 @@ std::optional<Face> Face::parse(const uint8_t *data, size_t len)
 			want = 0xFFFF;
 		f.loca_entries_ = std::min(want, f.loca_.size() / (f.loca_long_ ? 4u : 2u));
 	}
+	f.name_ = find_table(file, "name");
 	f.has_cff_ = !find_table(file, "CFF ").empty() || !find_table(file, "CFF2").empty();
 	const Bytes cmap = find_table(file, "cmap");
 	f.has_cmap_ = cmap.has(0, 4);
@@ -71,6 +72,66 @@ std::optional<Face> Face::parse(const uint8_t *data, size_t len)
 		}
 	}
 	return f;
+}
+
+// ---- name ------------------------------------------------------------------------------
+std::vector<std::pair<uint16_t, std::string>> Face::names() const
+{
+	std::vector<std::pair<uint16_t, std::string>> out;
+	if (!name_.has(0, 6))
+		return out;
+	const uint16_t version = name_.u16(0), count = name_.u16(2);
+	const size_t storage_off = name_.u16(4);
+	if (version > 1 || !name_.has(6, (size_t)count * 12))
+		return out;
+	const Bytes storage = name_.from(std::max(storage_off, (size_t)6 + (size_t)count * 12));
+	for (uint16_t i = 0; i < count; i++) {
+		const size_t rec = 6 + (size_t)i * 12;
+		const uint16_t platform = name_.u16(rec), encoding = name_.u16(rec + 2), name_id = name_.u16(rec + 6);
+		const size_t len = name_.u16(rec + 8), off = name_.u16(rec + 10);
+		if (!storage.has(off, len))
+			break; // the crate's iterator ends at the first record whose bytes are out of range
+		std::string text;
+		const bool unicode = platform == 0 || (platform == 3 && (encoding == 0 || encoding == 1));
+		if (unicode) { // String::from_utf16 over the big-endian units; an unpaired surrogate -> None -> ""
+			bool ok = true;
+			for (size_t k = 0; k + 1 < len && ok; k += 2) {
+				uint32_t c = storage.u16(off + k);
+				if (c >= 0xD800 && c <= 0xDBFF) {
+					const uint32_t lo = (k + 3 < len) ? storage.u16(off + k + 2) : 0;
+					if (lo >= 0xDC00 && lo <= 0xDFFF) {
+						c = 0x10000 + ((c - 0xD800) << 10) + (lo - 0xDC00);
+						k += 2;
+					} else {
+						ok = false;
+					}
+				} else if (c >= 0xDC00 && c <= 0xDFFF) {
+					ok = false;
+				}
+				if (!ok)
+					break;
+				if (c < 0x80) {
+					text.push_back((char)c);
+				} else if (c < 0x800) {
+					text.push_back((char)(0xC0 | (c >> 6)));
+					text.push_back((char)(0x80 | (c & 63)));
+				} else if (c < 0x10000) {
+					text.push_back((char)(0xE0 | (c >> 12)));
+					text.push_back((char)(0x80 | ((c >> 6) & 63)));
+					text.push_back((char)(0x80 | (c & 63)));
+				} else {
+					text.push_back((char)(0xF0 | (c >> 18)));
+					text.push_back((char)(0x80 | ((c >> 12) & 63)));
+					text.push_back((char)(0x80 | ((c >> 6) & 63)));
+					text.push_back((char)(0x80 | (c & 63)));
+				}
+			}
+			if (!ok)
+				text.clear();
+		}
+		out.emplace_back(name_id, std::move(text));
+	}
+	return out;
 }
 
 // ---- hmtx ------------------------------------------------------------------------------

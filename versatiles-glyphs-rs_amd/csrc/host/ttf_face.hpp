@@ -12,6 +12,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <optional>
+#include <string>
+#include <utility>
 #include <vector>
 
 namespace vg {
@@ -69,6 +71,10 @@ public:
 	// (ttf-parser renders those through curve_to) is refused at load time instead of yielding empty glyphs.
 	bool has_glyf_outlines() const { return !glyf_.empty() && !loca_.empty(); }
 	bool has_cff_outlines() const { return has_cff_; }
+	// Face::names() (src/font/metadata.rs:92-97): every record of the `name` table in table order as
+	// (name_id, Name::to_string().unwrap_or_default()): UTF-16BE records of the Unicode platform and of
+	// the Windows platform (encodings 0 and 1) decoded to UTF-8, every other record an empty string.
+	std::vector<std::pair<uint16_t, std::string>> names() const;
 	// Sorted unique code points that a unicode cmap subtable maps to a glyph.
 	std::vector<uint32_t> unicode_codepoints() const;
 
@@ -83,7 +89,7 @@ private:
 
 	std::optional<Bytes> glyph_data(uint16_t glyph_id) const;
 
-	Bytes hmtx_, loca_, glyf_;
+	Bytes hmtx_, loca_, glyf_, name_;
 	std::vector<CmapSubtable> cmap_;
 	uint16_t units_per_em_ = 0, num_glyphs_ = 0, num_hmetrics_ = 0;
 	bool loca_long_ = false, has_cmap_ = false, has_cff_ = false;

@@ -20,6 +20,7 @@
 // not HBM bound: see DESIGN.md §4 for the algorithm, the exactness argument and the roofline.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 
 #include "sdf_kernels.h"
 
@@ -271,8 +272,25 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
                                                       const double *__restrict__ seg_sy,
                                                       const double *__restrict__ seg_ex,
                                                       const double *__restrict__ seg_ey,
-                                                      uint8_t *__restrict__ out, const float4 *__restrict__ boxes)
+                                                      uint8_t *__restrict__ out, const float4 *__restrict__ boxes,
+                                                      unsigned long long *__restrict__ dbg)
 {
+	// ABL & 256 (development builds): s_memtime stamps per phase, summed per wave into dbg[region]
+	// (cdna_hip_programming.md, "In-kernel stamps"); read the SHARES, never this build's run time.
+	unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+	auto STAMP = [&](int region) {
+		if constexpr ((ABL & 256) != 0) {
+			unsigned long long t;
+			__builtin_amdgcn_sched_barrier(0);
+			asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+			__builtin_amdgcn_sched_barrier(0);
+			if (region >= 0)
+				st_acc[region] += t - st_last;
+			st_last = t;
+		}
+	};
+	(void)dbg;
+	STAMP(-1);
 	constexpr uint32_t GRP = 8, NGRP = FCHUNK / GRP; // 32 groups per chunk: one mask bit each
 	static_assert(NGRP == 32 && TPB == FCHUNK, "one candidate bit per group, one staging thread per record");
 	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
@@ -297,7 +315,9 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 
 	const uint32_t r_first = p0 / g.w, r_last = (p_end - 1) / g.w;
 	const int y_hi = (int)(g.h - 1 - r_first), y_lo = (int)(g.h - 1 - r_last);
-	const uint32_t stride = g.w + 1;
+	// one histogram row = w + 1 cells (the last one collects "no column left of the pixel row's end"), padded to an odd
+	// stride so that the per-row scans after the chunk loop (one thread per row) spread over the LDS banks
+	const uint32_t stride = (g.w + 1) | 1u;
 	const double band_lo = (double)y_lo + y0c, band_hi = (double)y_hi + y0c; // lowest / highest sample row of the span
 	const uint32_t n_delta = (r_last - r_first + 1) * stride; // <= DELTA_CAP (host-checked)
 	for (uint32_t i = tid; i < n_delta; i += TPB)
@@ -315,7 +335,9 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	const bool use_boxes = boxes != nullptr && !(ABL & 128) && g.n_seg > 2 * FCHUNK;
 	for (uint32_t c0 = 0; c0 < g.n_seg; c0 += FCHUNK) {
 		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
+		STAMP(0); // prologue / loop overhead
 		__syncthreads(); // previous chunk fully consumed (and s_delta / state initialised on the first trip)
+		STAMP(1); // wait at the chunk-top barrier
 		if (use_boxes) {
 			// ---- chunk box test (workgroup-uniform).  Skip the chunk if its box lies strictly outside the
 			// span's band of sample rows (so none of its segments crosses one of them: no winding
@@ -395,7 +417,9 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			if ((tid & 63) == 0)
 				atomicMax(&s_mbits, mb);
 		}
+		STAMP(2); // stage: loads, records, crossings, coordinate bound
 		__syncthreads();
+		STAMP(3); // wait at the post-stage barrier
 		const float Mc = __uint_as_float(s_mbits);
 		const bool sane = Mc < 1.0e6f;   // else: no usable f32 bound -> every segment is evaluated exactly
 		const bool bounded = Mc < 4096.0f; // group bounds have a useful margin
@@ -427,13 +451,17 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL * 1.004f; // 1.004: see phase 1
 			}
 		}
+		STAMP(4); // group bounds
 		__syncthreads();
+		STAMP(5); // wait at the post-bounds barrier
 
 		const float4 *q_vx = reinterpret_cast<const float4 *>(s_vx), *q_vy = reinterpret_cast<const float4 *>(s_vy);
 		const float4 *q_dx = reinterpret_cast<const float4 *>(s_dx), *q_dy = reinterpret_cast<const float4 *>(s_dy);
 		const float4 *q_inv = reinterpret_cast<const float4 *>(s_inv);
 		const float M = Mc;
 		const float e64 = 5.6843418860808015e-14f * M * (M + mabs0 + M); // 2^-44 M (M + Mabs)
+		// h(F) + e64 as one fused expression in the decide step: h(F) = 1.001 (64 u M sqrt(F) + 32 u F + 2^-34 M^2)
+		const float herr_c1 = 1.001f * 3.814697265625e-06f * M, herr_c3 = 1.001f * 5.820766091346741e-11f * M * M + e64;
 
 		// ---- sweep: every tile of the span against the staged chunk ----
 #pragma unroll 1
@@ -442,12 +470,16 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			// instead of parking 96 VGPRs of them across it
 			asm volatile("" ::: "memory");
 			const uint32_t o = p0 + k * TPB + tid;
+			// a wave whose 64 pixels all lie past the end of the bitmap (last tile of the glyph) has nothing to do
+			if (p0 + k * TPB + (tid & ~63u) >= npix)
+				continue;
 			const uint32_t oc = o < npix ? o : npix - 1;
 			const uint32_t row = oc / g.w;
 			const uint32_t x = oc - row * g.w;
 			const uint32_t y = g.h - 1 - row;
 			const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
 			float ub2 = st_ub2[k * TPB + tid];
+			STAMP(0);
 
 			// ---- phase 1: candidate groups of this lane ----
 			uint32_t cand = n_groups >= 32 ? 0xFFFFFFFFu : ((1u << n_groups) - 1u);
@@ -509,6 +541,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			}
 
 
+			STAMP(6); // phase 1
 			// ---- phase 2: smallest f32 filter value over the lane's candidate groups (F >= +0: unsigned
 			// order of the bits is float order) ----
 			uint32_t k1 = 0xFFFFFFFFu;
@@ -586,6 +619,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			// are functions of the bin q = floor(32 sqrt(C) + 1/2) (renderer_precise.rs:71-79: 191 - q
 			// outside, 191 + q inside); if the whole interval falls into one bin no f64 work is needed.
 			// The reference's own roundings move 32 sqrt(C) by < 1e-12, the f32 evaluation by < 1e-4. ----
+			STAMP(7); // phase 2 (pooling + filter rounds)
 			bool have = false;
 			uint32_t b_in = 255u, b_out = 0u;
 			double best = __builtin_huge_val(); // rtree_segments.rs:57
@@ -601,28 +635,34 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					exact_lds(j);
 				have = true;
 			} else if (k1 != 0xFFFFFFFFu) {
+				// C lies in [f1 - e, f1 + e], e = h(f1) + e64 (one fused expression; the 1.001 of filter_err covers its
+				// roundings).  Bin number of the reference's quantisation: floor(32 sqrt(C) + 1/2).  With 8 e <= f1,
+				// |32 sqrt(C) - 32 sqrt(f1)| <= 16.55 e / sqrt(f1) on the whole interval (sqrt is concave: upper side
+				// e / (2 sqrt f1), lower side e / (sqrt f1 + sqrt(f1 - e)) <= 1.034 e / (2 sqrt f1)), so if
+				// s = 32 sqrt(f1) + 1/2 is farther than dl = 17 e / sqrt(f1) + 3e-4 from the next integer (3e-4: f32
+				// roundings of s, < 3e-5, and of the reference's own arithmetic, < 1e-12) every C of the interval
+				// falls into bin floor(s).  Beyond C = 35.9 (32 sqrt(C) + 1/2 >= 192) both bytes are saturated (0 / 255)
+				// whatever the bin is.  NaN anywhere -> every comparison false -> not decided -> exact evaluation.
 				const float f1 = __uint_as_float(k1);
-				float U = f1 + filter_err(f1, M) + e64;
+				const float sq = __builtin_sqrtf(f1);
+				const float e = __builtin_fmaf(herr_c1, sq, __builtin_fmaf(1.9092559814453125e-06f, f1, herr_c3));
+				float U = f1 + e;
+				const float uf = U * (1.0f + 1.0f / 1048576.0f);
+				ub2 = uf < ub2 ? uf : ub2; // bounds the later chunks' candidates too
+				const float s = __builtin_fmaf(32.0f, sq, 0.5f);
+				const float dl = __builtin_fmaf(17.0f * e, __builtin_amdgcn_rcpf(sq), 3.0e-4f);
+				const float fr = __builtin_amdgcn_fractf(s);
+				const float mn = fr < 1.0f - fr ? fr : 1.0f - fr;
+				const bool far = f1 - e > 35.9f;
+				const bool decided = far || (8.0f * e <= f1 && mn > dl);
+				if (decided) {
+					const int q = far ? 200 : (int)s;
+					b_in = (uint32_t)min(191 + q, 255);
+					b_out = (uint32_t)max(191 - q, 0);
+				}
 				if (!(U >= 0.0f))
 					U = __builtin_inff();
-				bool decided = false;
-				if (U < 1.0e30f) {
-					const float cc = 3.83e-6f * M;
-					float LB = f1 > cc * cc ? f1 - filter_err(f1, M) - e64 : 0.0f;
-					LB = LB > 0.0f ? LB : 0.0f;
-					LB = LB < 38.0f ? LB : 38.0f;
-					const float Uc = U < 38.0f ? U : 38.0f;
-					const float q_lo = __builtin_floorf(__builtin_sqrtf(LB) * 32.0f + (0.5f - 2.0e-4f));
-					const float q_hi = __builtin_floorf(__builtin_sqrtf(Uc) * 32.0f + (0.5f + 2.0e-4f));
-					if (q_lo == q_hi) {
-						const int q = (int)q_lo;
-						b_in = (uint32_t)min(191 + q, 255);
-						b_out = (uint32_t)max(191 - q, 0);
-						decided = true;
-					}
-					const float uf = U * (1.0f + 1.0f / 1048576.0f);
-					ub2 = uf < ub2 ? uf : ub2; // bounds the later chunks' candidates too
-				}
+				STAMP(8); // decide
 				if (!decided && !(ABL & 4)) {
 					// Rescan of the lane's candidate groups against a threshold Tk with L(Tk) > U (L increasing
 					// above it): fixed-point iteration for the crossing, pushed up, then VERIFIED; if the check
@@ -658,6 +698,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					have = true;
 				}
 			}
+			STAMP(9); // exact fallback (rescan + f64)
 			if (have) {
 				b_in = quantise(best, true);
 				b_out = quantise(best, false);
@@ -668,22 +709,43 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			b_out = max(b_out, old >> 8);
 			st_byte[k * TPB + tid] = (uint16_t)(b_in | (b_out << 8));
 			st_ub2[k * TPB + tid] = ub2;
+			STAMP(10); // quantise + state update
 		}
 	}
 
-	// ---- winding number = prefix sum of the row's histogram up to the pixel's column; pick the byte ----
-	__syncthreads(); // n_seg == 0: the initial state / zeroed histogram must be visible
+	// ---- winding number = prefix sum of the row's histogram up to the pixel's column (renderer_precise.rs:58-66).
+	// One thread per row turns its row into inclusive prefix sums in place (exact integer sums, any order);
+	// every pixel then reads one cell and picks its byte. ----
+	__syncthreads(); // all crossings recorded (n_seg == 0: the initial state / zeroed histogram must be visible)
+	{
+		const uint32_t n_rows = r_last - r_first + 1;
+		for (uint32_t r = tid; r < n_rows; r += TPB) {
+			int *drow = s_delta + r * stride;
+			int acc = 0;
+#pragma unroll 4
+			for (uint32_t c = 0; c < g.w; c++) {
+				acc += drow[c];
+				drow[c] = acc;
+			}
+		}
+	}
+	__syncthreads();
 	for (uint32_t k = 0; k < T; k++) {
 		const uint32_t o = p0 + k * TPB + tid;
 		if (o < npix) {
 			const uint32_t row = o / g.w;
 			const uint32_t x = o - row * g.w;
-			int wn = 0;
-			const int *drow = s_delta + (row - r_first) * stride;
-			for (uint32_t c = 0; c <= x; c++)
-				wn += drow[c];
+			const int wn = s_delta[(row - r_first) * stride + x];
 			const uint32_t sb = st_byte[k * TPB + tid];
 			out[g.out_off + o] = (uint8_t)(wn != 0 ? (sb & 255u) : (sb >> 8));
+		}
+	}
+	STAMP(11); // epilogue: winding prefix sums, stores
+	if constexpr ((ABL & 256) != 0) {
+		if (dbg != nullptr && lane == 0) {
+			for (int r = 0; r < 12; r++)
+				atomicAdd(&dbg[r], st_acc[r]);
+			atomicAdd(&dbg[12], 1ull);
 		}
 	}
 }
@@ -717,7 +779,7 @@ extern "C" int vgsdf_kernel_known(int kernel)
 {
 #ifdef VGSDF_DEV_VARIANTS
 	switch (kernel) {
-	case 10: case 12: case 22: case 23: case 30: case 45: case 51: case 52: case 53: case 54: case 55: case 56: case 57:
+	case 10: case 12: case 22: case 23: case 30: case 45: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58:
 		return 1;
 	}
 #endif
@@ -736,7 +798,7 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
 #define VG_LAUNCH_SPAN(A)                                                                                 \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
-	                   sx, sy, ex, ey, out, (const float4 *)boxes)
+	                   sx, sy, ex, ey, out, (const float4 *)boxes, (unsigned long long *)nullptr)
 	if (variant == 1)
 		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
 		                   tiles, n_tiles, sx, sy, ex, ey, out);
@@ -767,6 +829,26 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_SPAN(64);
 	else if (variant == 57) // A/B: no chunk-box skipping
 		VG_LAUNCH_SPAN(128);
+	else if (variant == 58) { // diagnostic: s_memtime stamps per phase; prints the shares of wave time on stderr
+		static unsigned long long *d_dbg = nullptr;
+		if (!d_dbg && hipMalloc(&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+			return (int)hipErrorOutOfMemory;
+		(void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), stream);
+		hipLaunchKernelGGL((vgsdf::sdf_tiles_span<256>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles, sx, sy, ex,
+		                   ey, out, (const float4 *)boxes, d_dbg);
+		unsigned long long h[16];
+		(void)hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream);
+		(void)hipStreamSynchronize(stream);
+		static const char *names[12] = {"overhead", "wait chunk-top barrier", "stage", "wait post-stage barrier", "group bounds",
+		                                "wait post-bounds barrier", "phase 1", "phase 2", "decide", "exact fallback",
+		                                "quantise+state", "epilogue"};
+		unsigned long long tot = 0;
+		for (int r = 0; r < 12; r++)
+			tot += h[r];
+		std::fprintf(stderr, "[vgsdf stamps] %llu waves, %.0f ticks per wave\n", h[12], h[12] ? (double)tot / (double)h[12] : 0.0);
+		for (int r = 0; r < 12; r++)
+			std::fprintf(stderr, "[vgsdf stamps]   %-26s %6.2f %%\n", names[r], tot ? 100.0 * (double)h[r] / (double)tot : 0.0);
+	}
 	else if (variant == 30) // bounded groups on 256-pixel tiles
 		VG_LAUNCH_HIER(0, false);
 	else if (variant == 45) // ... exact evaluation only where the byte is undecided

@@ -265,7 +265,8 @@ static void build_descs_and_tiles(const vgsdf_batch *in, vgsdf::GlyphDesc *hd, u
 	const uint64_t delta_cap = (uint64_t)vgsdf_filtered_delta_cap();
 	// rows touched by T consecutive tiles, times w+1 columns, must fit the winding histogram
 	// (32-bit division: this runs per glyph on the end-to-end path)
-	auto fits = [&](uint32_t w, uint32_t T) { return (uint64_t)((VGSDF_TILE_PIXELS * T - 2u) / w + 2u) * ((uint64_t)w + 1u) <= delta_cap; };
+	// (the kernel pads a histogram row of w + 1 cells to an odd stride: at most w + 2)
+	auto fits = [&](uint32_t w, uint32_t T) { return (uint64_t)((VGSDF_TILE_PIXELS * T - 2u) / w + 2u) * ((uint64_t)w + 2u) <= delta_cap; };
 	// span list (default kernel): a workgroup takes up to 4 consecutive tiles of one glyph, the
 	// largest count whose rows fit; the entry is (glyph, first pixel | count)
 	const char *sm = std::getenv("VGSDF_SPAN_MAX");

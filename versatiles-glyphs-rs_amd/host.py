@@ -41,6 +41,10 @@ VGFONT_SYMBOLS = [
     "vg_name_to_id", "vg_manager_block_counts", "vg_manager_render_glyphs", "vg_manager_timings",
     "vg_manager_render_block", "vg_manager_render_blocks", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
     "vg_glyph_batch_free", "vg_manager_record_outlines", "vg_outline_batch_view", "vg_outline_batch_free", "vg_pbf_encode",
+    "vg_manager_scan", "vg_manager_font_ids", "vg_manager_font_file_names", "vg_parse_font_name", "vg_manager_generate_name",
+    "vg_encode_codeblocks", "vg_manager_index_json", "vg_manager_families_json", "vg_writer_new_tar_path",
+    "vg_writer_new_tar_fd", "vg_writer_new_dir", "vg_writer_write_file", "vg_writer_write_directory", "vg_writer_finish",
+    "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
 ]
 
 _bound = False
@@ -85,6 +89,32 @@ def _L():
         L.vg_pbf_encode.restype = C.c_long
         L.vg_pbf_encode.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PbfGlyph), C.POINTER(C.c_void_p), C.c_int,
                                     vp, C.c_size_t]
+        L.vg_manager_scan.argtypes = [vp, C.c_char_p]
+        for f in (L.vg_manager_font_ids, L.vg_manager_index_json, L.vg_manager_families_json):
+            f.restype = C.c_long
+            f.argtypes = [vp, vp, C.c_size_t]
+        L.vg_manager_font_file_names.restype = C.c_long
+        L.vg_manager_font_file_names.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+        L.vg_parse_font_name.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint16),
+                                         C.c_char_p]
+        L.vg_manager_generate_name.restype = C.c_long
+        L.vg_manager_generate_name.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_size_t]
+        L.vg_encode_codeblocks.restype = C.c_long
+        L.vg_encode_codeblocks.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
+        L.vg_writer_new_tar_path.restype = vp
+        L.vg_writer_new_tar_path.argtypes = [C.c_char_p, C.c_int64]
+        L.vg_writer_new_tar_fd.restype = vp
+        L.vg_writer_new_tar_fd.argtypes = [C.c_int, C.c_int64]
+        L.vg_writer_new_dir.restype = vp
+        L.vg_writer_new_dir.argtypes = [C.c_char_p]
+        L.vg_writer_write_file.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.vg_writer_write_directory.argtypes = [vp, C.c_char_p]
+        L.vg_writer_finish.argtypes = [vp]
+        L.vg_writer_free.argtypes = [vp]
+        L.vg_writer_free.restype = None
+        L.vg_manager_render_glyphs_to.argtypes = [vp, vp, vp]
+        L.vg_manager_write_index_json.argtypes = [vp, vp]
+        L.vg_manager_write_families_json.argtypes = [vp, vp]
         _bound = True
     return L
 
@@ -211,8 +241,56 @@ class FontManager:
         return name_to_id(name)
 
     def add_path(self, path):
+        """manager.rs:39-53: the file's own name table decides the font id."""
         if _L().vg_manager_add_path(self._h, str(path).encode()) != 0:
-            raise NotImplementedError(_err())
+            raise RuntimeError(_err())
+
+    def add_paths(self, paths):
+        for p in paths:
+            self.add_path(p)
+
+    def scan(self, path):
+        """recurse.rs:104-133 (fonts.json aware; directory entries in sorted order)."""
+        if _L().vg_manager_scan(self._h, str(path).encode()) != 0:
+            raise RuntimeError(_err())
+
+    def _text(self, fn, *args) -> bytes:
+        need = fn(self._h, *args, None, 0)
+        if need < 0:
+            raise RuntimeError(_err())
+        buf = C.create_string_buffer(need + 1)
+        fn(self._h, *args, buf, need + 1)
+        return buf.raw[:need]
+
+    def font_ids(self):
+        t = self._text(_L().vg_manager_font_ids).rstrip(b"\0").decode()
+        return t.split("\n") if t else []
+
+    def font_file_names(self, font_id: str):
+        t = self._text(_L().vg_manager_font_file_names, font_id.encode()).rstrip(b"\0").decode()
+        return t.split("\n") if t else []
+
+    def generate_name(self, font_id: str, file_index: int = 0) -> str:
+        return self._text(_L().vg_manager_generate_name, font_id.encode(), file_index).rstrip(b"\0").decode()
+
+    def index_json(self) -> bytes:
+        return self._text(_L().vg_manager_index_json)
+
+    def families_json(self) -> bytes:
+        return self._text(_L().vg_manager_families_json)
+
+    def render_glyphs_to(self, writer: "NativeWriter", renderer: Renderer):
+        """render_glyphs into a native sink (tar stream / directory)."""
+        if _L().vg_manager_render_glyphs_to(self._h, renderer._h, writer._h) != 0:
+            raise RuntimeError(_err())
+
+    def write_index_json(self, writer: "NativeWriter"):
+        if _L().vg_manager_write_index_json(self._h, writer._h) != 0:
+            raise RuntimeError(_err())
+
+    def write_families_json(self, writer: "NativeWriter"):
+        if _L().vg_manager_write_families_json(self._h, writer._h) != 0:
+            raise RuntimeError(_err())
 
     def block_counts(self, font_id: str) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint32)
@@ -307,6 +385,69 @@ class FontManager:
             self.close()
         except Exception:
             pass
+
+
+class NativeWriter:
+    """src/writer: Writer::new_tar / Writer::new_file, implemented natively (csrc/host/writers.cpp)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError(_err())
+        self._h = handle
+
+    @classmethod
+    def new_tar(cls, path, mtime: int = -1):
+        return cls(_L().vg_writer_new_tar_path(str(path).encode(), mtime))
+
+    @classmethod
+    def new_tar_fd(cls, fd: int, mtime: int = -1):
+        return cls(_L().vg_writer_new_tar_fd(fd, mtime))
+
+    @classmethod
+    def new_file(cls, folder):
+        return cls(_L().vg_writer_new_dir(str(folder).encode()))
+
+    def write_file(self, path: str, data: bytes):
+        if _L().vg_writer_write_file(self._h, path.encode(), data, len(data)) != 0:
+            raise RuntimeError(_err())
+
+    def write_directory(self, path: str):
+        if _L().vg_writer_write_directory(self._h, path.encode()) != 0:
+            raise RuntimeError(_err())
+
+    def finish(self):
+        if _L().vg_writer_finish(self._h) != 0:
+            raise RuntimeError(_err())
+
+    def close(self):
+        if self._h:
+            _L().vg_writer_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_font_name(family: str, ps_name: str):
+    """(family, style, weight, width) — src/font/parse_font_name.rs:214-291"""
+    fam = C.create_string_buffer(1024)
+    style = C.create_string_buffer(16)
+    width = C.create_string_buffer(16)
+    weight = C.c_uint16(0)
+    _L().vg_parse_font_name(family.encode(), ps_name.encode(), fam, len(fam), style, C.byref(weight), width)
+    return fam.value.decode(), style.value.decode(), int(weight.value), width.value.decode()
+
+
+def encode_codeblocks(codepoints) -> str:
+    """src/font/index_files.rs:65-103"""
+    cps = np.ascontiguousarray(codepoints, dtype=np.uint32)
+    need = _L().vg_encode_codeblocks(cps.ctypes.data, cps.size, None, 0)
+    buf = C.create_string_buffer(need)
+    _L().vg_encode_codeblocks(cps.ctypes.data, cps.size, buf, need)
+    return buf.value.decode()
 
 
 class DummyWriter:
