@@ -25,9 +25,13 @@ def test_name_to_id(vg):
     assert vg.name_to_id("---") == ""
 
 
-def test_add_path_is_out_of_scope(vg):
-    with pytest.raises(NotImplementedError):
-        vg.FontManager(False).add_path(FIRA)
+def test_add_path_names_the_font_from_its_name_table(vg):
+    # manager.rs:39-53, metadata.rs:136-144; more in tests/test_ingestion_and_sinks.py
+    m = vg.FontManager(False)
+    m.add_path(FIRA)
+    assert m.font_ids() == ["fira_sans_regular"]
+    with pytest.raises(RuntimeError):
+        m.add_path(FIRA.parent / "no such file.ttf")
 
 
 def test_get_blocks_counts(fira_mgr):

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	__shared__ __attribute__((aligned(16))) float s_vx[FCHUNK], s_vy[FCHUNK], s_dx[FCHUNK], s_dy[FCHUNK], s_inv[FCHUNK];
 	__shared__ double e_vx[FCHUNK], e_vy[FCHUNK], e_wx[FCHUNK], e_wy[FCHUNK]; // exact endpoints
 	__shared__ int s_delta[DELTA_CAP];
-	__shared__ uint32_t s_mbits;
+	__shared__ uint32_t s_mbits[2]; // coordinate bound of the chunk being staged (slot = parity of processed chunks)
 	__shared__ __attribute__((aligned(16))) float s_gx[NGRP], s_gy[NGRP], s_gr[NGRP]; // anchor, radius
 	__shared__ float st_ub2[SPAN_TILES * TPB];    // per pixel: upper bound of the squared distance so far
 	__shared__ uint16_t st_byte[SPAN_TILES * TPB]; // per pixel: byte if inside (low), byte if outside (high)
@@ -328,6 +328,9 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	}
 
 	const float wh = (float)max(g.w, g.h);
+	uint32_t par = 0;
+	if (tid == 0)
+		s_mbits[0] = __float_as_uint(wh);
 	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
 	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
 
@@ -356,21 +359,18 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			if (dy > 0.0f && __builtin_fmaf(dy, dy, dx * dx) > R * R)
 				continue; // NaN anywhere -> comparison false -> the chunk is processed
 		}
-		if (tid == 0)
-			s_mbits = __float_as_uint(wh);
-		__syncthreads();
-
-		// ---- stage (thread i <-> record i): exact endpoints, f32 record, coordinate bound, crossings ----
+		// ---- stage (thread i <-> record i): exact endpoints, f32 record, coordinate bound, group bounds,
+		// row crossings.  Everything a thread needs from other threads here comes from lanes of its own wave
+		// (a group of 8 records, the crossings of the wave's 64 segments), so there is one workgroup barrier
+		// behind the stage and none inside it. ----
+		constexpr float INFL = 1.0f + 1.0f / 512.0f;
 		{
 			const uint32_t i = tid;
 			float mf = 0.0f;
-			if (i >= cnt) { // pad the chunk with records that can never win (F = 2e36)
-				s_vx[i] = 1.0e18f;
-				s_vy[i] = 1.0e18f;
-				s_dx[i] = 0.0f;
-				s_dy[i] = 0.0f;
-				s_inv[i] = 0.0f;
-			} else {
+			float fvx = 1.0e18f, fvy = 1.0e18f, fdx = 0.0f, fdy = 0.0f, finv = 0.0f; // padding: a record that can never win (F = 2e36)
+			uint32_t nrow = 0; // sample rows of the span this thread's segment crosses: yy in [ya, ya + nrow)
+			int ya = 0;
+			if (i < cnt) {
 				const uint32_t s = g.seg_off + c0 + i;
 				const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
 				e_vx[i] = vx;
@@ -379,81 +379,124 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				e_wy[i] = wy;
 				const double dx = wx - vx, dy = wy - vy;
 				const double l2 = dx * dx + dy * dy;
-				const double rvx = vx - (double)g.x0, rvy = vy - (double)g.y0;
-				const double rwx = wx - (double)g.x0, rwy = wy - (double)g.y0;
-				s_vx[i] = (float)rvx;
-				s_vy[i] = (float)rvy;
-				s_dx[i] = (float)dx;
-				s_dy[i] = (float)dy;
-				s_inv[i] = (l2 > 1e-20 && l2 < 1e30) ? (float)(1.0 / l2) : 0.0f;
-				const double m = fmax(fmax(fabs(rvx), fabs(rvy)), fmax(fabs(rwx), fabs(rwy)));
-				mf = (float)m * 1.000001f;               // round up
+				fvx = (float)(vx - (double)g.x0);
+				fvy = (float)(vy - (double)g.y0);
+				fdx = (float)dx;
+				fdy = (float)dy;
+				// 1 / |d|^2 to ~3 units of f32 roundoff (conversion + v_rcp_f32): the closest point of the f32 record
+				// moves by <= 17 u M along the segment, inside the 28.6 u M the filter's error bound h(F) allows
+				finv = (l2 > 1e-20 && l2 < 1e30) ? __builtin_amdgcn_rcpf((float)l2) : 0.0f;
+				// coordinate bound from the f32 values (end point as v + d: <= 2.5 ulp(M) off), rounded up
+				mf = fmaxf(fmaxf(fabsf(fvx), fabsf(fvy)), fmaxf(fabsf(fvx + fdx), fabsf(fvy + fdy))) * 1.00001f;
 				mf = mf >= 0.0f ? mf : __builtin_inff(); // NaN -> inf ("no usable bound")
-				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y
-				// Rows crossed: lo <= py < hi with py = yy + y0c exactly as the reference forms it.  Most
-				// segments of a real font are a fraction of a pixel tall and most lie outside the span's band
-				// of rows: two exact compares reject those before the integer bracket is computed, and the
-				// upper end of the range is found by walking (py < hi) instead of a second bracket.
+				// crossings, renderer_precise.rs:41-51: up (+1) s.y <= py < e.y; down (-1) e.y <= py < s.y.
+				// Rows crossed: lo <= py < hi with py = yy + y0c exactly as the reference forms it.  Most segments of
+				// a real font are a fraction of a pixel tall and most lie outside the span's band of rows: two
+				// exact compares reject those before the integer brackets are computed.
 				const bool up = vy < wy;
 				const double lo = up ? vy : wy, hi = up ? wy : vy;
 				if (!(ABL & 1) && vy != wy && hi > band_lo && lo <= band_hi) {
-					const int ya = first_ge(lo, y0c, y_lo, y_hi + 1);
-					for (int yy = ya; yy <= y_hi; yy++) {
-						const double pyy = (double)yy + y0c;
-						if (!(pyy < hi))
-							break;
-						const double tc = (pyy - vy) / dy;
-						const double xc = vx + tc * dx;               // :45-46 / :48-49
-						const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
-						if (k < (int)g.w)
-							atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
-					}
+					ya = first_ge(lo, y0c, y_lo, y_hi + 1);
+					const int yb = first_ge(hi, y0c, y_lo, y_hi + 1); // first row with py >= hi
+					nrow = yb > ya ? (uint32_t)(yb - ya) : 0u;
 				}
 			}
+			s_vx[i] = fvx;
+			s_vy[i] = fvy;
+			s_dx[i] = fdx;
+			s_dy[i] = fdy;
+			s_inv[i] = finv;
 			// coordinate bound: wave maximum first, one LDS atomic per wave (non-negative floats order like uints)
 			uint32_t mb = __float_as_uint(mf);
 			for (int sh = 32; sh > 0; sh >>= 1)
 				mb = max(mb, (uint32_t)__shfl_xor((int)mb, sh));
-			if ((tid & 63) == 0)
-				atomicMax(&s_mbits, mb);
+			if (lane == 0)
+				atomicMax(&s_mbits[par], mb);
+
+			// ---- group bounds (8 consecutive records = 8 lanes): anchor = start vertex of the middle member, radius
+			// over all end points.  The pad that depends on the workgroup's coordinate bound is added in phase 1. ----
+			{
+				const uint32_t gb = tid & ~(GRP - 1);
+				const uint32_t ai = min(gb + GRP / 2, cnt - 1); // (a lane of this group whenever the group holds a record)
+				const float ax = __shfl(fvx, (int)(ai & 63u)), ay = __shfl(fvy, (int)(ai & 63u));
+				float r2 = 0.0f;
+				if (i < cnt) {
+					const float wx = fvx + fdx, wy = fvy + fdy;
+					const float ex = fvx - ax, ey = fvy - ay, fx = wx - ax, fy = wy - ay;
+					const float dv = __builtin_fmaf(ey, ey, ex * ex), dw = __builtin_fmaf(fy, fy, fx * fx);
+					r2 = dv > dw ? dv : dw;
+				}
+				for (int sh = 1; sh < (int)GRP; sh <<= 1) {
+					const float other = __shfl_xor(r2, sh);
+					r2 = other > r2 ? other : r2;
+				}
+				if ((tid & (GRP - 1)) == 0) {
+					const bool empty = gb >= cnt;
+					s_gx[tid / GRP] = empty ? 1.0e18f : ax;
+					s_gy[tid / GRP] = empty ? 1.0e18f : ay;
+					s_gr[tid / GRP] = empty ? 0.0f : __builtin_sqrtf(r2) * (INFL * INFL * 1.004f); // 1.004: see phase 1
+				}
+			}
+
+			// ---- row crossings of the wave's 64 segments, one (segment, row) pair per lane and round: a vertical stem
+			// crosses 20 rows, its neighbours none, and a per-thread loop would keep the whole workgroup waiting
+			// at the barrier for the one long segment (2.6 trips per wave on average, up to 24, against 7.5
+			// crossings per wave in total). ----
+			{
+				uint32_t incl = nrow; // inclusive prefix sum over the wave: DPP row shifts + row broadcasts
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false); // row_shr:1
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false); // row_shr:2
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false); // row_shr:4
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false); // row_shr:8
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				auto cross = [&](double vx, double vy, double dx, double dy, bool up, int yy) {
+					const double pyy = (double)yy + y0c;
+					const double tc = (pyy - vy) / dy;
+					const double xc = vx + tc * dx;               // :45-46 / :48-49
+					const int k = first_ge(xc, x0c, 0, (int)g.w); // first column with xc <= px (:63)
+					if (k < (int)g.w)
+						atomicAdd(&s_delta[(uint32_t)(y_hi - yy) * stride + (uint32_t)k], up ? -1 : 1); // wn -= sign
+				};
+				if (total != 0 && total <= QCAP) {
+					// (lane, row) pairs of the wave, pooled in LDS (rows of a span: < 1024, host-checked through DELTA_CAP)
+					uint32_t off = incl - nrow;
+					for (uint32_t r = 0; r < nrow; r++)
+						q_pair[wv][off++] = (uint16_t)((lane << 10) | (uint32_t)(y_hi - (ya + (int)r)));
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					for (uint32_t base = 0; base < total; base += 64) {
+						const uint32_t idx = base + lane;
+						if (idx < total) {
+							const uint32_t e = q_pair[wv][idx];
+							const uint32_t si = (tid & ~63u) + (e >> 10); // the segment's record (staged by this wave)
+							const double vx = e_vx[si], vy = e_vy[si], wx = e_wx[si], wy = e_wy[si];
+							cross(vx, vy, wx - vx, wy - vy, vy < wy, y_hi - (int)(e & 1023u));
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				} else if (total != 0) { // more pairs than the pool holds (tall glyphs): every thread walks its own rows
+					if (nrow != 0) {
+						const double vx = e_vx[i], vy = e_vy[i], wx = e_wx[i], wy = e_wy[i];
+						for (uint32_t r = 0; r < nrow; r++)
+							cross(vx, vy, wx - vx, wy - vy, vy < wy, ya + (int)r);
+					}
+				}
+			}
 		}
-		STAMP(2); // stage: loads, records, crossings, coordinate bound
+		STAMP(2); // stage: loads, records, crossings, coordinate bound, group bounds
 		__syncthreads();
 		STAMP(3); // wait at the post-stage barrier
-		const float Mc = __uint_as_float(s_mbits);
+		const float Mc = __uint_as_float(s_mbits[par]);
+		par ^= 1u;
+		if (tid == 0)
+			s_mbits[par] = __float_as_uint(wh); // the next processed chunk's accumulator (nobody touches it before the next chunk-top barrier)
 		const bool sane = Mc < 1.0e6f;   // else: no usable f32 bound -> every segment is evaluated exactly
 		const bool bounded = Mc < 4096.0f; // group bounds have a useful margin
 		const float pad = 0.01f + 1.0e-5f * Mc;
-		constexpr float INFL = 1.0f + 1.0f / 512.0f;
 		const uint32_t n_groups = (cnt + GRP - 1) / GRP;
-
-		// ---- group bounds: anchor = start vertex of the middle member, radius over all end points ----
-		{
-			const uint32_t gb = tid & ~(GRP - 1);
-			const uint32_t ai = min(gb + GRP / 2, cnt - 1);
-			const float ax = s_vx[ai], ay = s_vy[ai];
-			float r2 = 0.0f;
-			if (tid < cnt) {
-				const float vx = s_vx[tid], vy = s_vy[tid];
-				const float wx = vx + s_dx[tid], wy = vy + s_dy[tid];
-				const float ex = vx - ax, ey = vy - ay, fx = wx - ax, fy = wy - ay;
-				const float dv = __builtin_fmaf(ey, ey, ex * ex), dw = __builtin_fmaf(fy, fy, fx * fx);
-				r2 = dv > dw ? dv : dw;
-			}
-			for (int sh = 1; sh < (int)GRP; sh <<= 1) {
-				const float other = __shfl_xor(r2, sh);
-				r2 = other > r2 ? other : r2;
-			}
-			if ((tid & (GRP - 1)) == 0) {
-				const bool empty = gb >= cnt;
-				s_gx[tid / GRP] = empty ? 1.0e18f : ax;
-				s_gy[tid / GRP] = empty ? 1.0e18f : ay;
-				s_gr[tid / GRP] = empty ? 0.0f : (__builtin_sqrtf(r2) * INFL + pad) * INFL * 1.004f; // 1.004: see phase 1
-			}
-		}
-		STAMP(4); // group bounds
-		__syncthreads();
-		STAMP(5); // wait at the post-bounds barrier
 
 		const float4 *q_vx = reinterpret_cast<const float4 *>(s_vx), *q_vy = reinterpret_cast<const float4 *>(s_vy);
 		const float4 *q_dx = reinterpret_cast<const float4 *>(s_dx), *q_dy = reinterpret_cast<const float4 *>(s_dy);
@@ -517,7 +560,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				ub2 = __uint_as_float(dmin);
 				float U = (__builtin_sqrtf(ub2) * INFL + pad) * INFL;
 				U = U < 6.2f ? U : 6.2f; // SAT: beyond it the byte is saturated whatever the minimum is
-				const float Ui = U * 1.004f; // s_gr is stored with the same factor
+				const float Ui = (U + pad * INFL) * 1.004f; // s_gr is stored with the same factor; it lacks the pad of r_g
 				// One bit per group, 3-4 VALU ops each: tt = (U + r_g) 1.004, diff = tt^2 - D_g^2 (sign bit set
 				// <=> not a candidate; -3.4e38 for the groups past n_groups), shifted in with v_alignbit.  The
 				// bits arrive inverted and in reverse order: fixed once with v_not / v_bfrev.
