@@ -109,6 +109,18 @@ int vg_manager_render_glyphs(vg_manager *m, vg_renderer *r, vg_write_cb cb, void
 int vg_manager_render_glyphs_to(vg_manager *m, vg_renderer *r, vg_writer *w);
 int vg_manager_write_index_json(const vg_manager *m, vg_writer *w);
 int vg_manager_write_families_json(const vg_manager *m, vg_writer *w);
+/* Glyph-level shard of a font over `world` ranks: longest-processing-time-first on the
+ * estimated raster cost w*h*N of every glyph (from its recorded outline: exact point counts of the
+ * quadratic flattening, control-box area), identical on every rank.  owner[65536]: rank per code point,
+ * 0xFF = unmapped; cost[65536] (may be NULL): the estimates. */
+int vg_manager_shard_glyphs(const vg_manager *m, const char *font_id, uint32_t world, uint8_t *owner, double *cost);
+/* From now on every render / build_batch / record_outlines call of this manager sees only the glyphs
+ * that rank `rank` of `world` owns; every block is still emitted and its PBF holds this rank's glyphs
+ * only (a partial).  world <= 1 switches sharding off. */
+void vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world);
+/* Merges partial PBFs of ONE block (disjoint glyph subsets, same name and range) into the block's PBF:
+ * glyphs in ascending id, byte for byte what a single process encodes.  Returns the needed size. */
+long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap);
 /* A rank's shard: only the listed block starts (multiples of 256) of one font id. */
 int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id, const uint32_t *starts, int n,
                              vg_write_cb cb, void *user);

@@ -50,6 +50,8 @@ def main():
     n = b.n_glyphs if len(sys.argv) < 3 else min(b.n_glyphs, int(sys.argv[2]))
     tot = {k: dict(pairs=0, rounds=0, waves=0, lanes=0) for k in ("seq", "prepass", "ideal")}
     tilechunks = 0
+    global Z
+    Z = dict(act=0, zero=0, skip=0, skip_wrong=0)
     for g in range(n):
         a, e = int(b.seg_off[g]), int(b.seg_off[g + 1])
         w, h, x0, y0 = int(b.w[g]), int(b.h[g]), int(b.x0[g]), int(b.y0[g])
@@ -97,6 +99,21 @@ def main():
                 cw = np.zeros(padn, dtype=np.int64)
                 cw[:npix] = cnt
                 per_wave = cw.reshape(-1, 64).sum(axis=1)
+                if mode == "seq":
+                    # wave-level statistics: active waves (with pixels), waves without any pair, waves a box test could skip
+                    act = (np.arange(padn).reshape(-1, 64)[:, 0] < npix)
+                    Z["act"] += int(act.sum()); Z["zero"] += int(((per_wave == 0) & act).sum())
+                    # box test: chunk bbox vs wave pixel bbox with the wave's carried bound (sqrt of max ub2 over its pixels)
+                    ubw = np.full(padn, 0.0); ubw[:npix] = np.sqrt(np.minimum(ub2, 38.44)); ubw = ubw.reshape(-1, 64).max(axis=1)
+                    bx0, bx1 = min(sx[c0:c1].min(), ex[c0:c1].min()), max(sx[c0:c1].max(), ex[c0:c1].max())
+                    by0, by1 = min(sy[c0:c1].min(), ey[c0:c1].min()), max(sy[c0:c1].max(), ey[c0:c1].max())
+                    pxw = np.full(padn, np.nan); pxw[:npix] = px; pyw = np.full(padn, np.nan); pyw[:npix] = py
+                    pxw = pxw.reshape(-1, 64); pyw = pyw.reshape(-1, 64)
+                    with np.errstate(all="ignore"):
+                        wx0, wx1, wy0, wy1 = np.nanmin(pxw, 1), np.nanmax(pxw, 1), np.nanmin(pyw, 1), np.nanmax(pyw, 1)
+                    ddx = np.maximum(np.maximum(bx0 - wx1, wx0 - bx1), 0); ddy = np.maximum(np.maximum(by0 - wy1, wy0 - by1), 0)
+                    skip = act & (np.sqrt(ddx ** 2 + ddy ** 2) > ubw * 1.01 + 0.05)
+                    Z["skip"] += int(skip.sum()); Z["skip_wrong"] += int((skip & (per_wave > 0)).sum())
                 tot[mode]["pairs"] += int(cnt.sum())
                 tot[mode]["rounds"] += int(((per_wave + 63) // 64).sum())
                 tot[mode]["waves"] += len(per_wave)
@@ -108,6 +125,7 @@ def main():
             if mode == "seq":
                 tilechunks += ntile * len(chunks)
     print(f"{sys.argv[1]}: {n} glyphs, group size {GRP}, {tilechunks} tile-chunks")
+    print("  wave tile-chunks with pixels", Z["act"], "without any pair", Z["zero"], "skippable by chunk box vs carried bound", Z["skip"], "(of which wrongly)", Z["skip_wrong"])
     for mode, t in tot.items():
         print(f"  {mode:8s} pairs {t['pairs']:>10d}  per pixel-chunk {t['pairs'] / max(t['lanes'], 1):.2f}  rounds {t['rounds']:>8d} "
               f"per wave-tile-chunk {t['rounds'] / max(t['waves'], 1):.2f}  slot use {t['pairs'] / max(t['rounds'] * 64, 1):.2f}")

@@ -13,6 +13,6 @@ from .device import (  # noqa: F401
 )
 from .host import (  # noqa: F401
     DummyWriter, FontManager, GlyphBatchHost, NativeWriter, PbfGlyph, Renderer, encode_codeblocks, name_to_id, parse_font_name,
-    pbf_encode,
+    pbf_encode, pbf_merge,
 )
-from .dispatch import render_sharded, shard_blocks  # noqa: F401
+from .dispatch import render_sharded, render_sharded_glyphs, shard_blocks  # noqa: F401

@@ -98,6 +98,36 @@ int vg_manager_add_path(vg_manager *m, const char *path)
 	std::string err;
 	return m->m.add_path(path, &err) ? 0 : fail(err);
 }
+int vg_manager_shard_glyphs(const vg_manager *m, const char *font_id, uint32_t world, uint8_t *owner, double *cost)
+{
+	vg::GlyphShard sh;
+	std::string err;
+	if (!m->m.shard_glyphs(font_id, world, sh, &err))
+		return fail(err);
+	if (owner)
+		std::memcpy(owner, sh.owner.data(), sh.owner.size());
+	if (cost)
+		std::memcpy(cost, sh.cost.data(), sh.cost.size() * sizeof(double));
+	return 0;
+}
+
+void vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world) { m->m.set_glyph_shard(rank, world); }
+
+long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap)
+{
+	try {
+		std::vector<std::pair<const uint8_t *, size_t>> ps;
+		for (int i = 0; i < n; i++)
+			ps.emplace_back(parts[i], lens[i]);
+		const std::vector<uint8_t> v = vg::merge_pbf_partials(ps);
+		if (out && cap >= v.size())
+			std::memcpy(out, v.data(), v.size());
+		return (long)v.size();
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
 int vg_manager_scan(vg_manager *m, const char *path)
 {
 	std::string err;

@@ -382,7 +382,7 @@ bool FontManager::build_batch(const std::string &font_id, PackedBatch &out, std:
 		return false;
 	}
 	std::vector<Todo> tasks;
-	for (const GlyphBlock &b : it->second.blocks())
+	for (const GlyphBlock &b : task_blocks(it->first, it->second))
 		tasks.push_back(Todo{&it->first, b});
 	std::vector<Slice> slices;
 	tessellate_and_pack(tasks, 0, tasks.size(), slices, out);
@@ -406,11 +406,223 @@ bool FontManager::record_outlines(const std::string &font_id, OutlineBatch &out,
 		return false;
 	}
 	out.clear();
-	for (const GlyphBlock &b : it->second.blocks())
+	for (const GlyphBlock &b : task_blocks(it->first, it->second))
 		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
 			if (const FontFileEntry *f = b.glyphs[ci])
 				Renderer::record(f->face(), b.start_index + ci, out);
 	return true;
+}
+
+// ---- glyph-level sharding ---------------------------------------------------------------
+namespace {
+
+// Estimated raster cost of one recorded glyph: (bitmap area) x (segment count), the w*h*N of SURVEY.md §8e.
+// Segments: a quadratic Bezier is halved until |s + e - 2c|^2 <= 0.01 font units^2 (ring.rs:129-131); both
+// halves of a quadratic have exactly 1/4 of the parent's deviation, so the depth is uniform and the point
+// count is a power of two that follows from the control polygon alone.  Cubics (no fixture font has any) are
+// estimated the same way from their larger control deviation.  Area: bounding box of the control points,
+// scaled, plus the 3 px buffer on every side (renderer.rs:64-91).
+double estimate_cost(const vgsdf_outline_cmd *c, uint32_t n, double scale)
+{
+	if (n == 0)
+		return 1.0;
+	double segs = 0, minx = 1e300, miny = 1e300, maxx = -1e300, maxy = -1e300;
+	double lx = 0, ly = 0;
+	auto grow = [&](double x, double y) {
+		minx = std::min(minx, x), maxx = std::max(maxx, x);
+		miny = std::min(miny, y), maxy = std::max(maxy, y);
+	};
+	auto pieces = [](double dev2) {
+		double k = 1;
+		while (dev2 > 0.01 && k < 65536) {
+			dev2 /= 16;
+			k *= 2;
+		}
+		return k;
+	};
+	for (uint32_t i = 0; i < n; i++) {
+		const vgsdf_outline_cmd &q = c[i];
+		switch (q.kind) {
+		case 0: // move_to
+			break;
+		case 1: // line_to
+			segs += 1;
+			break;
+		case 2: { // quad_to
+			const double dx = lx + q.x - 2.0 * q.x1, dy = ly + q.y - 2.0 * q.y1;
+			segs += pieces(dx * dx + dy * dy);
+			grow(q.x1, q.y1);
+			break;
+		}
+		case 3: { // curve_to
+			const double dx = (double)q.x2 + q.x1 - (lx + q.x), dy = (double)q.y2 + q.y1 - (ly + q.y);
+			segs += pieces(dx * dx + dy * dy);
+			grow(q.x1, q.y1);
+			grow(q.x2, q.y2);
+			break;
+		}
+		default: // close: the closing segment
+			segs += 1;
+			continue;
+		}
+		grow(q.x, q.y);
+		lx = q.x, ly = q.y;
+	}
+	if (!(maxx >= minx))
+		return 1.0;
+	const double w = std::ceil((maxx - minx) * scale) + 2 * BUFFER + 1, h = std::ceil((maxy - miny) * scale) + 2 * BUFFER + 1;
+	return std::max(1.0, segs) * w * h;
+}
+
+} // namespace
+
+bool FontManager::shard_glyphs(const std::string &font_id, uint32_t world, GlyphShard &out, std::string *err) const
+{
+	auto it = fonts_.find(font_id);
+	if (it == fonts_.end() || world == 0 || world > 254) {
+		if (err)
+			*err = it == fonts_.end() ? "unknown font id " + font_id : "shard_glyphs: world must be 1..254";
+		return false;
+	}
+	out.world = world;
+	out.owner.assign(0x10000, 0xFF);
+	out.cost.assign(0x10000, 0.0);
+	out.load.assign(world, 0.0);
+	// costs from the recorded outlines of ALL glyphs (cheap: table walks, no flattening), first provider wins
+	OutlineBatch rec;
+	std::vector<std::pair<double, uint32_t>> order; // (cost, code point)
+	for (const GlyphBlock &b : it->second.blocks())
+		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+			if (const FontFileEntry *f = b.glyphs[ci]) {
+				const uint32_t cp = b.start_index + ci;
+				rec.clear();
+				double c = 1.0;
+				if (Renderer::record(f->face(), cp, rec))
+					c = estimate_cost(rec.cmds.data(), (uint32_t)rec.cmds.size(), rec.scale[0]);
+				out.cost[cp] = c;
+				order.emplace_back(c, cp);
+			}
+	// longest processing time first; ties by code point, so every rank computes the same assignment
+	std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+	for (const auto &e : order) {
+		uint32_t best = 0;
+		for (uint32_t r = 1; r < world; r++)
+			if (out.load[r] < out.load[best])
+				best = r;
+		out.owner[e.second] = (uint8_t)best;
+		out.load[best] += e.first;
+	}
+	return true;
+}
+
+void FontManager::set_glyph_shard(uint32_t rank, uint32_t world)
+{
+	shard_rank_ = rank;
+	shard_world_ = world ? world : 1;
+	shard_blocks_.clear();
+}
+
+const std::vector<GlyphBlock> &FontManager::task_blocks(const std::string &font_id, const FontWrapper &font) const
+{
+	if (shard_world_ <= 1)
+		return font.blocks();
+	auto it = shard_blocks_.find(font_id);
+	if (it != shard_blocks_.end() && it->second.size() == font.blocks().size())
+		return it->second;
+	GlyphShard sh;
+	std::string err;
+	if (!shard_glyphs(font_id, shard_world_, sh, &err))
+		throw std::runtime_error(err);
+	std::vector<GlyphBlock> blocks = font.blocks(); // copy, then drop what other ranks own
+	for (GlyphBlock &b : blocks)
+		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+			if (b.glyphs[ci] && sh.owner[b.start_index + ci] != shard_rank_) {
+				b.glyphs[ci] = nullptr;
+				b.count--;
+			}
+	return shard_blocks_[font_id] = std::move(blocks);
+}
+
+std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts)
+{
+	struct G {
+		uint32_t id;
+		const uint8_t *p; // the glyph message's payload
+		size_t n;
+	};
+	auto varint = [](const uint8_t *&p, const uint8_t *end, uint64_t &v) {
+		v = 0;
+		for (int sh = 0; p < end && sh < 64; sh += 7) {
+			const uint8_t b = *p++;
+			v |= (uint64_t)(b & 0x7F) << sh;
+			if (!(b & 0x80))
+				return true;
+		}
+		return false;
+	};
+	std::string name, range;
+	bool have = false;
+	std::vector<G> glyphs;
+	for (const auto &part : parts) {
+		const uint8_t *p = part.first, *end = p + part.second;
+		uint64_t len;
+		if (p == end || *p++ != 0x0A || !varint(p, end, len) || len != (uint64_t)(end - p))
+			throw std::runtime_error("merge_pbf_partials: not a glyphs PBF with one fontstack");
+		std::string nm, rg;
+		while (p < end) {
+			const uint8_t tag = *p++;
+			if (!varint(p, end, len) || len > (uint64_t)(end - p))
+				throw std::runtime_error("merge_pbf_partials: truncated field");
+			if (tag == 0x0A) {
+				nm.assign((const char *)p, (size_t)len);
+			} else if (tag == 0x12) {
+				rg.assign((const char *)p, (size_t)len);
+			} else if (tag == 0x1A) {
+				const uint8_t *q = p, *qe = p + len;
+				uint64_t id;
+				if (q == qe || *q++ != 0x08 || !varint(q, qe, id))
+					throw std::runtime_error("merge_pbf_partials: glyph without id");
+				glyphs.push_back(G{(uint32_t)id, p, (size_t)len});
+			} else {
+				throw std::runtime_error("merge_pbf_partials: unexpected field");
+			}
+			p += len;
+		}
+		if (have && (nm != name || rg != range))
+			throw std::runtime_error("merge_pbf_partials: parts of different blocks (" + name + "/" + range + " vs " + nm + "/" + rg + ")");
+		name = nm, range = rg, have = true;
+	}
+	std::stable_sort(glyphs.begin(), glyphs.end(), [](const G &a, const G &b) { return a.id < b.id; });
+	auto vsize = [](uint64_t v) {
+		size_t n = 1;
+		for (; v >= 0x80; v >>= 7)
+			n++;
+		return n;
+	};
+	auto put = [](std::vector<uint8_t> &o, uint64_t v) {
+		for (; v >= 0x80; v >>= 7)
+			o.push_back((uint8_t)(v | 0x80));
+		o.push_back((uint8_t)v);
+	};
+	size_t stack = 1 + vsize(name.size()) + name.size() + 1 + vsize(range.size()) + range.size();
+	for (const G &g : glyphs)
+		stack += 1 + vsize(g.n) + g.n;
+	std::vector<uint8_t> out;
+	out.reserve(1 + vsize(stack) + stack);
+	out.push_back(0x0A);
+	put(out, stack);
+	out.push_back(0x0A);
+	put(out, name.size());
+	out.insert(out.end(), name.begin(), name.end());
+	out.push_back(0x12);
+	put(out, range.size());
+	out.insert(out.end(), range.begin(), range.end());
+	for (const G &g : glyphs) {
+		out.push_back(0x1A);
+		put(out, g.n);
+		out.insert(out.end(), g.p, g.p + g.n);
+	}
+	return out;
 }
 
 void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
@@ -419,7 +631,7 @@ void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 	std::vector<Todo> tasks;
 	for (const auto &[name, font] : fonts_) {
 		writer.write_directory(name + "/");
-		for (const GlyphBlock &b : font.blocks())
+		for (const GlyphBlock &b : task_blocks(name, font))
 			tasks.push_back(Todo{&name, b});
 	}
 	run_tasks(tasks, writer, renderer);
@@ -431,7 +643,7 @@ void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const 
 	auto it = fonts_.find(font_id);
 	if (it == fonts_.end())
 		throw std::runtime_error("unknown font id " + font_id);
-	const std::vector<GlyphBlock> &blocks = it->second.blocks();
+	const std::vector<GlyphBlock> &blocks = task_blocks(it->first, it->second);
 	std::vector<Todo> tasks;
 	for (uint32_t start : block_starts) {
 		if (start % GLYPH_BLOCK_SIZE || start / GLYPH_BLOCK_SIZE >= blocks.size())

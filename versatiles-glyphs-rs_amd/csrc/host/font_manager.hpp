@@ -105,6 +105,16 @@ private:
 	mutable bool blocks_valid_ = false;
 };
 
+// Glyph-level shard of one font over `world` ranks: every mapped code point <= 0xFFFF has an
+// owner; costs are estimates of w*h*N (bitmap area x segment count) computed from the recorded outline
+// commands, identical on every rank, so all ranks derive the same assignment without talking to each other.
+struct GlyphShard {
+	uint32_t world = 1;
+	std::vector<uint8_t> owner; // [65536]: rank that renders the code point, 0xFF = not mapped by the font
+	std::vector<double> cost;   // [65536]: estimated cost (0 for unmapped)
+	std::vector<double> load;   // [world]: sum of estimated costs per rank
+};
+
 struct RenderTimings {
 	double tessellate_s = 0, pack_s = 0, device_s = 0, encode_s = 0, write_s = 0, total_s = 0;
 	uint64_t blocks = 0, glyphs = 0, rasters = 0, pixels = 0, segments = 0, pbf_bytes = 0;
@@ -139,6 +149,15 @@ public:
 	// (font, block) task list; blocks are independent: manager.rs:86-97).
 	void render_blocks(Writer &writer, const Renderer &renderer, const std::string &font_id,
 	                   const std::vector<uint32_t> &block_starts);
+
+	// ---- glyph-level sharding (the reference's unit is the (font, block) task, manager.rs:86-97; 45 non-empty,
+	// very unequal blocks do not balance over 8 GPUs, single glyphs do) ----
+	// Longest-processing-time-first assignment of the font's glyphs to `world` ranks by estimated cost.
+	bool shard_glyphs(const std::string &font_id, uint32_t world, GlyphShard &out, std::string *err) const;
+	// From now on render_glyphs / render_blocks / build_batch / record_outlines see only the glyphs rank `rank`
+	// owns (every block is still emitted: its PBF then holds this rank's glyphs only, a "partial" that
+	// merge_pbf_partials() combines with the other ranks').  world <= 1 switches sharding off.
+	void set_glyph_shard(uint32_t rank, uint32_t world);
 
 	// Host stage only: every rasterised glyph of one font, blocks in ascending order (the
 	// batch a bench/test keeps resident in HBM).  ids[i] = code point of rasterised glyph i.
@@ -196,6 +215,10 @@ private:
 	                         PackedBatch &out);
 	ThreadPool &pool();
 	unsigned worker_count() const;
+	// the block table tasks are built from: the font's own, or its copy filtered to this rank's glyphs
+	const std::vector<GlyphBlock> &task_blocks(const std::string &font_id, const FontWrapper &font) const;
+	uint32_t shard_rank_ = 0, shard_world_ = 1;
+	mutable std::map<std::string, std::vector<GlyphBlock>> shard_blocks_; // per font id, for (shard_rank_, shard_world_)
 	std::unique_ptr<ThreadPool> pool_;
 	std::vector<Worker> workers_;
 	PackedBatch packed_;
@@ -223,5 +246,11 @@ private:
 };
 
 std::string name_to_id(const std::string &name); // manager.rs:141-147
+
+// Combines partial PBFs of ONE block (same font name and range; each holds a disjoint subset of the block's
+// glyphs, e.g. one per rank of a glyph-level shard) into the block's PBF: glyph messages are taken as they
+// are and written in ascending id, so the result equals the PBF a single process encodes.  Throws
+// std::runtime_error on malformed input or when names / ranges differ.
+std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts);
 
 } // namespace vg

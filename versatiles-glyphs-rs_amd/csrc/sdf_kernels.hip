@@ -278,6 +278,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	// ABL & 256 (development builds): s_memtime stamps per phase, summed per wave into dbg[region]
 	// (cdna_hip_programming.md, "In-kernel stamps"); read the SHARES, never this build's run time.
 	unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+	unsigned long long cn_pairs = 0, cn_rounds = 0, cn_tc = 0, cn_fb = 0, cn_fbl = 0; // counters of the diagnostic build
 	auto STAMP = [&](int region) {
 		if constexpr ((ABL & 256) != 0) {
 			unsigned long long t;
@@ -328,9 +329,16 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 	}
 
 	const float wh = (float)max(g.w, g.h);
+	// Origin of every f32 quantity of the filter (records, anchors, pixel centres): the middle of the bitmap,
+	// an integer point.  The filter's error bound h(F) scales with M = the largest |coordinate| relative to
+	// that origin, so the middle halves it against the corner (x0, y0) (and with it the share of pixels whose
+	// byte needs the exact f64 evaluation).  Pixel centres stay exact in f32 (half-integers).
+	const int hw = (int)(g.w >> 1), hh = (int)(g.h >> 1);
+	const double ox = (double)g.x0 + (double)hw, oy = (double)g.y0 + (double)hh;
+	const float mpix = 0.5f * wh + 1.0f; // >= |pixel centre - origin| in both axes
 	uint32_t par = 0;
 	if (tid == 0)
-		s_mbits[0] = __float_as_uint(wh);
+		s_mbits[0] = __float_as_uint(mpix);
 	const float mabs0 = fmaxf(fmaxf(fabsf((float)g.x0), fabsf((float)g.y0)),
 	                          fmaxf(fabsf((float)g.x0 + (float)g.w), fabsf((float)g.y0 + (float)g.h)));
 
@@ -379,8 +387,8 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				e_wy[i] = wy;
 				const double dx = wx - vx, dy = wy - vy;
 				const double l2 = dx * dx + dy * dy;
-				fvx = (float)(vx - (double)g.x0);
-				fvy = (float)(vy - (double)g.y0);
+				fvx = (float)(vx - ox);
+				fvy = (float)(vy - oy);
 				fdx = (float)dx;
 				fdy = (float)dy;
 				// 1 / |d|^2 to ~3 units of f32 roundoff (conversion + v_rcp_f32): the closest point of the f32 record
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 		const float Mc = __uint_as_float(s_mbits[par]);
 		par ^= 1u;
 		if (tid == 0)
-			s_mbits[par] = __float_as_uint(wh); // the next processed chunk's accumulator (nobody touches it before the next chunk-top barrier)
+			s_mbits[par] = __float_as_uint(mpix); // the next processed chunk's accumulator (nobody touches it before the next chunk-top barrier)
 		const bool sane = Mc < 1.0e6f;   // else: no usable f32 bound -> every segment is evaluated exactly
 		const bool bounded = Mc < 4096.0f; // group bounds have a useful margin
 		const float pad = 0.01f + 1.0e-5f * Mc;
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			const uint32_t row = oc / g.w;
 			const uint32_t x = oc - row * g.w;
 			const uint32_t y = g.h - 1 - row;
-			const float rpx = (float)x + 0.5f, rpy = (float)y + 0.5f; // pixel centre relative to (x0,y0)
+			const float rpx = (float)((int)x - hw) + 0.5f, rpy = (float)((int)y - hh) + 0.5f; // pixel centre relative to the origin
 			float ub2 = st_ub2[k * TPB + tid];
 			STAMP(0);
 
@@ -623,6 +631,11 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
 				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
 				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				if constexpr ((ABL & 256) != 0) {
+					cn_pairs += total;
+					cn_rounds += (total + 63) / 64;
+					cn_tc += 1;
+				}
 				if (total <= QCAP && !(ABL & 64)) {
 					uint32_t off = incl - c;
 					q_min[wv][lane] = 0xFFFFFFFFu;
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					}
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 					__builtin_amdgcn_wave_barrier();
-					for (uint32_t base = 0; base < total; base += 64) {
+					for (uint32_t base = 0; base < total && !(ABL & 512); base += 64) {
 						const uint32_t idx = base + lane;
 						const bool valid = idx < total;
 						const uint32_t e = q_pair[wv][valid ? idx : base];
@@ -646,6 +659,8 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 					__builtin_amdgcn_wave_barrier();
 					k1 = q_min[wv][lane];
+					if (ABL & 1024)
+						k1 = 0xFFFFFFFFu;
 				} else {
 					uint32_t m = cand;
 					while (m) {
@@ -706,6 +721,11 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 				if (!(U >= 0.0f))
 					U = __builtin_inff();
 				STAMP(8); // decide
+				if constexpr ((ABL & 256) != 0) {
+					const unsigned long long amb = __ballot(!decided);
+					cn_fb += amb != 0;
+					cn_fbl += (unsigned long long)__builtin_popcountll(amb);
+				}
 				if (!decided && !(ABL & 4)) {
 					// Rescan of the lane's candidate groups against a threshold Tk with L(Tk) > U (L increasing
 					// above it): fixed-point iteration for the crossing, pushed up, then VERIFIED; if the check
@@ -789,6 +809,11 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			for (int r = 0; r < 12; r++)
 				atomicAdd(&dbg[r], st_acc[r]);
 			atomicAdd(&dbg[12], 1ull);
+			atomicAdd(&dbg[13], cn_pairs);
+			atomicAdd(&dbg[14], cn_rounds);
+			atomicAdd(&dbg[15], cn_tc);
+			atomicAdd(&dbg[16], cn_fb);
+			atomicAdd(&dbg[17], cn_fbl);
 		}
 	}
 }
@@ -822,7 +847,7 @@ extern "C" int vgsdf_kernel_known(int kernel)
 {
 #ifdef VGSDF_DEV_VARIANTS
 	switch (kernel) {
-	case 10: case 12: case 22: case 23: case 30: case 45: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58:
+	case 10: case 12: case 22: case 23: case 30: case 45: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 60: case 61:
 		return 1;
 	}
 #endif
@@ -872,14 +897,18 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		VG_LAUNCH_SPAN(64);
 	else if (variant == 57) // A/B: no chunk-box skipping
 		VG_LAUNCH_SPAN(128);
+	else if (variant == 60) // timing-only: pooled filter rounds kept, decide / fallback skipped
+		VG_LAUNCH_SPAN(1024);
+	else if (variant == 61) // timing-only: pair queue built, rounds and decide skipped
+		VG_LAUNCH_SPAN(512);
 	else if (variant == 58) { // diagnostic: s_memtime stamps per phase; prints the shares of wave time on stderr
 		static unsigned long long *d_dbg = nullptr;
-		if (!d_dbg && hipMalloc(&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+		if (!d_dbg && hipMalloc(&d_dbg, 24 * sizeof(unsigned long long)) != hipSuccess)
 			return (int)hipErrorOutOfMemory;
-		(void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), stream);
+		(void)hipMemsetAsync(d_dbg, 0, 24 * sizeof(unsigned long long), stream);
 		hipLaunchKernelGGL((vgsdf::sdf_tiles_span<256>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles, sx, sy, ex,
 		                   ey, out, (const float4 *)boxes, d_dbg);
-		unsigned long long h[16];
+		unsigned long long h[24];
 		(void)hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream);
 		(void)hipStreamSynchronize(stream);
 		static const char *names[12] = {"overhead", "wait chunk-top barrier", "stage", "wait post-stage barrier", "group bounds",
@@ -891,6 +920,9 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 		std::fprintf(stderr, "[vgsdf stamps] %llu waves, %.0f ticks per wave\n", h[12], h[12] ? (double)tot / (double)h[12] : 0.0);
 		for (int r = 0; r < 12; r++)
 			std::fprintf(stderr, "[vgsdf stamps]   %-26s %6.2f %%\n", names[r], tot ? 100.0 * (double)h[r] / (double)tot : 0.0);
+		std::fprintf(stderr, "[vgsdf counts] wave tile-chunks %llu, pairs %llu (%.1f per wave tile-chunk), rounds %llu (%.2f), wave fallback events %llu (%.3f per wave tile-chunk), undecided lanes %llu\n",
+		             h[15], h[13], h[15] ? (double)h[13] / (double)h[15] : 0.0, h[14], h[15] ? (double)h[14] / (double)h[15] : 0.0, h[16],
+		             h[15] ? (double)h[16] / (double)h[15] : 0.0, h[17]);
 	}
 	else if (variant == 30) // bounded groups on 256-pixel tiles
 		VG_LAUNCH_HIER(0, false);

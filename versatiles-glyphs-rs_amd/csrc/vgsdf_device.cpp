@@ -565,7 +565,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	if (n) {
 		vgsdf::GlyphDesc *hd = (vgsdf::GlyphDesc *)(hs + off_desc);
 		uint2 *ht = (uint2 *)(hs + off_tiles);
-		build_descs_and_tiles(in, hd, ht, b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 59));
+		build_descs_and_tiles(in, hd, ht, b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 69));
 		if (n_seg && !direct) {
 			std::memcpy(hs + off_sx, in->seg_sx, sizeof(double) * n_seg);
 			std::memcpy(hs + off_sy, in->seg_sy, sizeof(double) * n_seg);
@@ -637,7 +637,7 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	const uint32_t n_main = v == 1 ? 0 : b->n_main;
 	// kernel id understood by vgsdf_launch_tiles
 	const int k_main = v == 0 ? 50 : (v == 13 ? 10 : v);
-	if (b->stats.n_tiles != 0 && (k_main >= 50 && k_main <= 59) != b->span_list) {
+	if (b->stats.n_tiles != 0 && (k_main >= 50 && k_main <= 69) != b->span_list) {
 		ctx->err = "vgsdf_batch_launch: the batch was uploaded for a different kernel variant (tile list layout)";
 		return VGSDF_E_ARG;
 	}
@@ -927,7 +927,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	auto *hd = (vgsdf::GlyphDesc *)fe.h_stage.p;
 	auto *ht = (uint2 *)((uint8_t *)fe.h_stage.p + desc_bytes);
 	const double tr4 = fe_now();
-	build_descs_and_tiles(&view, hd, ht, &b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 59));
+	build_descs_and_tiles(&view, hd, ht, &b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 69));
 	const double tr5 = fe_now();
 	FE_TRY(hipMemcpyAsync(fe.descs_tiles.p, fe.h_stage.p, desc_bytes + sizeof(uint2) * (size_t)b.stats.n_tiles, hipMemcpyHostToDevice, st));
 	b.d_glyphs = (vgsdf::GlyphDesc *)fe.descs_tiles.p;

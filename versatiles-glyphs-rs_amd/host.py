@@ -45,6 +45,7 @@ VGFONT_SYMBOLS = [
     "vg_encode_codeblocks", "vg_manager_index_json", "vg_manager_families_json", "vg_writer_new_tar_path",
     "vg_writer_new_tar_fd", "vg_writer_new_dir", "vg_writer_write_file", "vg_writer_write_directory", "vg_writer_finish",
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
+    "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
 ]
 
 _bound = False
@@ -90,6 +91,11 @@ def _L():
         L.vg_pbf_encode.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PbfGlyph), C.POINTER(C.c_void_p), C.c_int,
                                     vp, C.c_size_t]
         L.vg_manager_scan.argtypes = [vp, C.c_char_p]
+        L.vg_manager_shard_glyphs.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp]
+        L.vg_manager_set_glyph_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.vg_manager_set_glyph_shard.restype = None
+        L.vg_pbf_merge.restype = C.c_long
+        L.vg_pbf_merge.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t]
         for f in (L.vg_manager_font_ids, L.vg_manager_index_json, L.vg_manager_families_json):
             f.restype = C.c_long
             f.argtypes = [vp, vp, C.c_size_t]
@@ -292,6 +298,18 @@ class FontManager:
         if _L().vg_manager_write_families_json(self._h, writer._h) != 0:
             raise RuntimeError(_err())
 
+    def shard_glyphs(self, font_id: str, world: int):
+        """-> (owner u8[65536] with 0xFF = unmapped, estimated cost f64[65536]); SURVEY.md §8e."""
+        owner = np.empty(65536, dtype=np.uint8)
+        cost = np.empty(65536, dtype=np.float64)
+        if _L().vg_manager_shard_glyphs(self._h, font_id.encode(), world, owner.ctypes.data, cost.ctypes.data) != 0:
+            raise RuntimeError(_err())
+        return owner, cost
+
+    def set_glyph_shard(self, rank: int, world: int):
+        """Later render / build_batch calls see only rank's glyphs (world <= 1: off)."""
+        _L().vg_manager_set_glyph_shard(self._h, rank, world)
+
     def block_counts(self, font_id: str) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint32)
         if _L().vg_manager_block_counts(self._h, font_id.encode(), out.ctypes.data_as(C.POINTER(C.c_uint32))) != 0:
@@ -429,6 +447,19 @@ class NativeWriter:
             self.close()
         except Exception:
             pass
+
+
+def pbf_merge(parts) -> bytes:
+    """Partial PBFs of one block (disjoint glyph subsets) -> the block's PBF."""
+    parts = [bytes(p) for p in parts]
+    arr = (C.c_char_p * len(parts))(*parts)
+    lens = (C.c_size_t * len(parts))(*[len(p) for p in parts])
+    need = _L().vg_pbf_merge(arr, lens, len(parts), None, 0)
+    if need < 0:
+        raise RuntimeError(_err())
+    out = np.empty(need, dtype=np.uint8)
+    _L().vg_pbf_merge(arr, lens, len(parts), out.ctypes.data, need)
+    return out.tobytes()
 
 
 def parse_font_name(family: str, ps_name: str):
