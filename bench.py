@@ -7,19 +7,26 @@
 One "step" = one pass of the hot path (the SDF raster kernel) over one batch: every glyph
 of the workload font, segments already tessellated by the product's C++ host stage and
 RESIDENT IN HBM when the timed region starts (BASELINE.json: configs[1], "Noto Sans
-Regular, full codepoint set, 1xMI355X").  value = glyphs/s over all ranks (each rank
-renders its own replica of the batch: weak scaling, no data-path collective; RCCL is used
-only for the barrier, the max-over-ranks time and the final {blocks, glyphs, pixels}
-counter reduce).
+Regular, full codepoint set, 1xMI355X").  value = glyphs/s over all ranks.
 
-Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle —
-the C restatement of the reference algorithm, oracle/ — on the same already tessellated
-batch on the host cores; the oracle is never on the measured GPU path.
+  default           every rank renders its own replica of the batch: weak scaling, no data-path
+                    collective; RCCL only for the barrier, the max-over-ranks time and the
+                    {blocks, glyphs, pixels} counter reduce.
+  --sharded         ONE font's glyphs are split over the ranks (glyph-level, cost-balanced:
+                    FontManager.shard_glyphs; BASELINE.json configs[3]:
+                    `--workload noto_all --sharded`): strong scaling, total work fixed.
+
+The timed region is at least --min-ms long (default 50 ms): if K steps are shorter, more steps are
+timed and `steps` says how many (`steps_requested` = K).  Rank 0 prints ONE JSON line.  The CPU
+baseline leg (rank 0, N=1 only) times the oracle — the C restatement of the reference algorithm,
+oracle/ — on the same tessellated batch on the host cores; the oracle is never on the measured path.
 """
 import argparse
+import hashlib
 import importlib.util
 import json
 import os
+import platform
 import sys
 import time
 from pathlib import Path
@@ -61,23 +68,45 @@ def workload_files(name):
     return disp, paths
 
 
-def traffic_bytes(workload, variant):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950
-    correction applied) in a separate profiling run: profiles/traffic.json, written by
-    tools/summarize_profile.py.  None when this (workload, variant) has not been profiled."""
+def kernel_source_sha256():
+    """Identity of the raster kernel's code: the PMC-derived numbers in profiles/traffic.json are only
+    reported when they were collected on exactly these sources."""
+    h = hashlib.sha256()
+    for f in ("sdf_kernels.hip", "sdf_kernels.h"):
+        h.update((ROOT / "versatiles-glyphs-rs_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()
+
+
+def pmc_entry(workload, variant):
+    """PMC numbers of a separate rocprofv3 run (tools/profile.sh + tools/summarize_profile.py ->
+    profiles/traffic.json); None unless they belong to the kernel sources of this build."""
     try:
         d = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-        return d[f"{workload}:{variant}"]["bytes_per_launch"]
+        e = d[f"{workload}:{variant}"]
+        return e if e.get("kernel_source_sha256") == kernel_source_sha256() else None
     except Exception:
         return None
 
 
-def pmc_value(workload, variant, key):
+def cpu_model():
     try:
-        d = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-        return d[f"{workload}:{variant}"].get(key)
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return platform.processor() or "unknown"
+
+
+def time_resident(ctx, db, steps, warmup, min_ms):
+    """W warm-up launches, then K' >= K launches with K' chosen so that the region lasts >= min_ms.
+    -> (steps timed, HIP-event ms of those launches)"""
+    for _ in range(max(warmup, 0)):
+        db.launch()
+    ctx.sync()
+    est = db.time(max(1, min(steps, 10))) / max(1, min(steps, 10))  # ms per launch (untimed probe)
+    k = max(steps, int(min_ms / max(est, 1e-6)) + 1)
+    return k, est
 
 
 def main():
@@ -85,10 +114,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-ms", type=float, default=50.0, help="minimum length of the timed region")
     ap.add_argument("--workload", default="noto_regular", choices=sorted(WORKLOADS))
+    ap.add_argument("--sharded", action="store_true", help="split the font's glyphs over the ranks (strong scaling)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of the other font workloads")
     ap.add_argument("--synthetic-outlines", type=int, default=0, help="outlines per rank for --workload synthetic")
     args = ap.parse_args()
 
@@ -139,17 +171,25 @@ def main():
     # ---- host stage (product C++): fonts -> SoA batch ---------------------------------
     disp, paths = workload_files(args.workload)
     synthetic = args.workload == "synthetic"
+    if synthetic and args.sharded:
+        sys.exit("--sharded splits a font; the synthetic outlines are already one index range per rank")
     t0 = time.perf_counter()
+    shard_info = None
     if synthetic:
         from versatiles_glyphs_rs_amd import synthetic as S
         n_out = args.synthetic_outlines or SYNTHETIC_PER_RANK
         class _HB:  # same shape as GlyphBatchHost: .batch
             batch = S.make_batch(rank * n_out, n_out)   # rank r renders outlines [r*n, (r+1)*n)
         hb, mgr, fid = _HB, None, None
-        args.no_e2e = True
+        args.no_e2e = args.no_configs = True
     else:
         mgr = vg.FontManager(True)
         fid = mgr.add_font_with_name(disp, paths)
+        if args.sharded and world > 1:
+            owner, est = mgr.shard_glyphs(fid, world)
+            loads = [float(est[owner == r].sum()) for r in range(world)]
+            shard_info = {"ranks": world, "estimated_cost_max_over_mean": max(loads) / (sum(loads) / world)}
+            mgr.set_glyph_shard(rank, world)     # this rank's glyphs only, from here on
         hb = mgr.build_batch(fid)
     host_s = time.perf_counter() - t0
 
@@ -163,13 +203,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 0)):
-        db.launch()
-    ctx.sync()
+    steps, _ = time_resident(ctx, db, args.steps, args.warmup, args.min_ms)
+    if dist is not None:  # every rank times the same number of steps
+        k = torch.tensor([steps], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        steps = int(k.item())
 
     barrier()
     t0 = time.perf_counter()
-    kernel_ms_total = db.time(args.steps)   # HIP events on the launch stream, K launches, waits for the last
+    kernel_ms_total = db.time(steps)   # HIP events on the launch stream, K' launches, waits for the last
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -182,17 +224,19 @@ def main():
         c = torch.tensor(counters, dtype=torch.int64, device=coll_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)        # the only RCCL payload: 24 bytes
         counters = [int(v) for v in c.tolist()]
+        if args.sharded:
+            counters[0] = 256                           # one font's blocks, whoever assembles them
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    steps = args.steps
     glyphs_total = counters[1] * steps
     value = glyphs_total / elapsed
     kernel_s = kernel_ms_total * 1e-3 / steps
     alg_gbs = st["alg_bytes"] / kernel_s * 1e-9
+    pmc = pmc_entry(args.workload, args.variant) if not args.sharded else None
 
     out = {
         "metric": "glyphs/sec (SDF raster, Noto Sans Regular full BMP set)" if args.workload == "noto_regular"
@@ -201,25 +245,32 @@ def main():
         "unit": "glyphs/s",
         "n_gpus": world,
         "steps": steps,
+        "steps_requested": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.sharded else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": ("synthetic outlines (SplitMix64 seed 0x5DF61F95), each rank its own index range" if synthetic else
-                 "reference testdata font committed in-repo (no network); every rank renders its own replica"),
+                 "reference testdata font committed in-repo (no network); " +
+                 ("the font's glyphs are split over the ranks" if args.sharded else "every rank renders its own replica")),
         "config": {
             "workload": (f"synthetic: {st['n_glyphs']} outlines x 1024 segments, 70x70 px per rank" if synthetic else
                          f"{args.workload}: {disp}, {len(paths)} file(s), all BMP code points"),
             "glyphs_per_step_per_gpu": st["n_glyphs"],
+            "glyphs_per_step_all_gpus": counters[1],
             "segments": st["n_segments"],
             "pixels": st["n_pixels"],
             "pair_evals": st["n_pairs"],
             "tiles": st["n_tiles"],
             "kernel_variant": args.variant,
-            "parallelism": f"replica x{world} (glyph batches shard with no exchange)",
+            "parallelism": (f"glyph-level shard x{world}: longest-processing-time-first on estimated w*h*N per glyph, "
+                            "identical on every rank (no exchange in the timed step; partial PBFs meet at the block "
+                            "owners afterwards)" if args.sharded else
+                            f"replica x{world} (glyph batches shard with no exchange)"),
             "collectives": ("none" if world == 1 else f"{backend}: barrier, max(time), sum of 3 counters"),
+            "timed_region_ms": elapsed * 1e3,
         },
         "mpixel_sdf_per_s": counters[2] * steps / elapsed * 1e-6,
         "roofline": {
@@ -228,7 +279,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": alg_gbs / HBM_PEAK_GBS,
-            "traffic": traffic_bytes(args.workload, args.variant),
+            "traffic": pmc["bytes_per_launch"] if pmc else None,
             "kernel": ("sdf_tiles_span<0>: the only kernel of a step (bounded groups over spans of tiles)"
                        if args.variant == 0 else f"variant {args.variant}"),
             "kernel_ms_avg": kernel_s * 1e3,
@@ -237,17 +288,21 @@ def main():
                     "where the byte is undecided); see `valu`",
         },
         "valu": {
-            "insts_per_wave": pmc_value(args.workload, args.variant, "valu_insts_per_wave"),
-            "ginst_per_s_per_simd": pmc_value(args.workload, args.variant, "valu_ginst_per_s_per_simd"),
-            "issue_frac": pmc_value(args.workload, args.variant, "valu_issue_frac"),
+            "insts_per_wave": pmc.get("valu_insts_per_wave") if pmc else None,
+            "busy_frac": pmc.get("valu_busy_frac") if pmc else None,
+            "cycles_per_inst": pmc.get("valu_cycles_per_inst") if pmc else None,
+            "pmc_kernel_ms": pmc.get("kernel_ms") if pmc else None,
             "brute_pairs_per_s": st["n_pairs"] / kernel_s,
-            "note": "VALU instruction issue rate per SIMD from the PMC pass recorded in profiles/traffic.json (null if "
-                    "this workload/variant was not profiled) against the measured full-rate f32 issue of gfx950, 0.96 G "
-                    "inst/s/SIMD (tools/ubench/valu_rate.hip); brute_pairs_per_s = pixels x segments of the batch / "
-                    "kernel time, i.e. the rate a brute-force evaluation would need",
+            "note": "from the rocprofv3 PMC passes recorded in profiles/traffic.json, reported only when that file was "
+                    "collected on the kernel sources of this build (else null): VALU instructions per wave, share of SIMD "
+                    "cycles with the VALU busy (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles)), busy cycles "
+                    "per instruction; brute_pairs_per_s = pixels x segments of the batch / kernel time, the rate a "
+                    "brute-force evaluation would need",
         },
         "host_stage_s": host_s,
     }
+    if shard_info:
+        out["config"]["shard"] = shard_info
 
     # ---- CPU baseline: oracle raster on the same tessellated batch, host cores ---------
     if world == 1 and not args.no_cpu_baseline:
@@ -264,49 +319,69 @@ def main():
         for mode, label in ((O.PRECISE, "±8 px envelope filter"), (O.BRUTE, "all segments")):
             if synthetic and mode == O.BRUTE:
                 continue
-            ref, secs = O.sdf_render_batch(sample, mode, cores)
-            if not (ref == got).all():
-                out["parity"] = f"MISMATCH vs oracle ({label})"
-            if best is None or secs < best[0]:
-                best = (secs, label)
+            for _ in range(1 if synthetic else 3):
+                ref, secs = O.sdf_render_batch(sample, mode, cores)
+                if not (ref == got).all():
+                    out["parity"] = f"MISMATCH vs oracle ({label})"
+                if best is None or secs < best[0]:
+                    best = (secs, label, mode)
         out.setdefault("parity", "bit-exact vs oracle on the compared sample")
+        _, secs1 = O.sdf_render_batch(sample, best[2], 1)   # the reference has --single-thread (recurse.rs:51-53)
         out["cpu_baseline"] = {
             "value": n_sample / best[0],
             "unit": "glyphs/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"{n_sample} glyphs of the {args.workload} batch, once, raster only, same tessellated "
-                      f"segments; faster of the oracle's candidate rules: {best[1]}",
+            "sample": f"{n_sample} glyphs of the {args.workload} batch, raster only, same tessellated segments, best of "
+                      f"3 passes; faster of the oracle's candidate rules: {best[1]}",
             "seconds": best[0],
+            "single_thread": {"value": n_sample / secs1, "seconds": secs1},
+            "cpu_model": cpu_model(),
+            "threads_note": f"threads = CPU affinity of this process ({len(os.sched_getaffinity(0))}), no cap "
+                            f"(VG_CPU_THREADS overrides); machine reports {os.cpu_count()} logical CPUs",
         }
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
 
     # ---- end-to-end (fonts -> PBF bytes), reported beside the headline, never as `value` --
+    def e2e_of(m, renderer, fe):
+        m.set_device_front_end(fe)
+        w = vg.DummyWriter()
+        m.render_glyphs(w, renderer)  # warm-up with a collecting writer: every block arrives
+        n_files, n_bytes = len(w.files), sum(len(v) for v in w.files.values())
+        best = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            m.render_glyphs(None, renderer)  # native NULL sink: no Python callback per block
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        tm = m.timings()
+        assert tm["pbf_bytes"] == n_bytes, (tm["pbf_bytes"], n_bytes)
+        return {"glyphs_per_s": tm["glyphs"] / best, "seconds": best, "pbf_files": n_files, "pbf_bytes": n_bytes,
+                "phases_s": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
+
+    def cpu_e2e(font_paths, font_id):
+        """the oracle's whole path (fonts -> PBF bytes), one task per (font, block) like manager.rs:117-121"""
+        from oracle import oracle as O
+        fonts = [O.Font(p) for p in font_paths]
+        best = None
+        for mode in (O.PRECISE, O.BRUTE):
+            secs, ctr = O.render_all(fonts, font_id, mode, O.default_threads())
+            if best is None or secs < best[0]:
+                best = (secs, ctr, "±8 px envelope filter" if mode == O.PRECISE else "all segments")
+        return {"glyphs_per_s": best[1]["glyphs"] / best[0], "seconds": best[0], "threads": O.default_threads(),
+                "candidate_rule": best[2]}
+
+    r = None
     if world == 1 and not args.no_e2e:
         r = vg.Renderer.new_precise(local_rank)
         out["e2e"] = {"note": "parse -> outline -> (flatten) -> H2D -> kernels -> D2H -> PBF encode, PCIe inclusive, "
                               "best of 5 warm runs; device_front_end = flattening/closing/scale/bbox on the GPU"}
         for label, fe in (("device_front_end", True), ("host_tessellation", False)):
-            mgr.set_device_front_end(fe)
-            w = vg.DummyWriter()
-            mgr.render_glyphs(w, r)  # warm-up with a collecting writer: every block arrives
-            n_files, n_bytes = len(w.files), sum(len(v) for v in w.files.values())
-            best = best_py = None
-            for _ in range(5):
-                t0 = time.perf_counter()
-                mgr.render_glyphs(None, r)  # native NULL sink: no Python callback per block
-                dt = time.perf_counter() - t0
-                best = dt if best is None else min(best, dt)
-            tm = mgr.timings()
-            assert tm["pbf_bytes"] == n_bytes, (tm["pbf_bytes"], n_bytes)
-            for _ in range(3):
-                t0 = time.perf_counter()
-                mgr.render_glyphs(vg.DummyWriter(), r)
-                dt = time.perf_counter() - t0
-                best_py = dt if best_py is None else min(best_py, dt)
-            out["e2e"][label] = {"glyphs_per_s": tm["glyphs"] / best, "seconds": best,
-                                 "seconds_with_python_writer": best_py, "pbf_files": n_files, "pbf_bytes": n_bytes,
-                                 "phases_s": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
+            out["e2e"][label] = e2e_of(mgr, r, fe)
+            t0 = time.perf_counter()
+            mgr.render_glyphs(vg.DummyWriter(), r)
+            out["e2e"][label]["seconds_with_python_writer"] = time.perf_counter() - t0
+        mgr.set_device_front_end(True)
         out["e2e"]["gpu_path_glyphs_per_s"] = out["e2e"]["device_front_end"]["glyphs_per_s"]
         # many small fonts in one manager (every fixture file as its own font): submissions are grouped
         many = vg.FontManager(True)
@@ -324,12 +399,35 @@ def main():
         out["e2e"]["all_21_fixture_fonts_as_separate_fonts"] = {"glyphs_per_s": tm["glyphs"] / best, "seconds": best,
                                                                  "glyphs": tm["glyphs"], "pbf_bytes": tm["pbf_bytes"]}
         if not args.no_cpu_baseline:
-            from oracle import oracle as O
-            fonts = [O.Font(p) for p in paths]
-            secs, ctr = O.render_all(fonts, fid, O.BRUTE, O.default_threads())
-            out["e2e"]["cpu_port_glyphs_per_s"] = ctr["glyphs"] / secs
-            out["e2e"]["cpu_threads"] = O.default_threads()
-            out["e2e"]["gpu_over_cpu"] = out["e2e"]["gpu_path_glyphs_per_s"] / out["e2e"]["cpu_port_glyphs_per_s"]
+            c = cpu_e2e(paths, fid)
+            out["e2e"]["cpu_port"] = c
+            out["e2e"]["gpu_over_cpu"] = out["e2e"]["gpu_path_glyphs_per_s"] / c["glyphs_per_s"]
+
+    # ---- the other font workloads, same measurements, in the same line ---------------------
+    if world == 1 and not args.no_configs and not args.sharded:
+        out["configs"] = []
+        for wl in ("fira", "noto_regular", "noto_all"):
+            if wl == args.workload:
+                continue
+            d2, p2 = workload_files(wl)
+            m2 = vg.FontManager(True)
+            f2 = m2.add_font_with_name(d2, p2)
+            hb2 = m2.build_batch(f2)
+            db2 = ctx.upload(hb2.batch)
+            k2, _ = time_resident(ctx, db2, 20, 5, args.min_ms)
+            ms2 = db2.time(k2) / k2
+            st2 = db2.stats()
+            ent = {"workload": f"{wl}: {d2}, {len(p2)} file(s), all BMP code points", "glyphs": st2["n_glyphs"],
+                   "segments": st2["n_segments"], "pixels": st2["n_pixels"], "steps": k2, "kernel_ms": ms2,
+                   "glyphs_per_s": st2["n_glyphs"] / (ms2 * 1e-3), "mpixel_sdf_per_s": st2["n_pixels"] / (ms2 * 1e-3) * 1e-6,
+                   "roofline_frac_hbm": st2["alg_bytes"] / (ms2 * 1e-3) * 1e-9 / HBM_PEAK_GBS}
+            db2.free()
+            del hb2
+            if not args.no_e2e:
+                ent["e2e_glyphs_per_s"] = e2e_of(m2, r, True)["glyphs_per_s"]
+                if not args.no_cpu_baseline and wl != "noto_all":  # (the 20-file CPU pass takes several seconds)
+                    ent["e2e_cpu_port_glyphs_per_s"] = cpu_e2e(p2, f2)["glyphs_per_s"]
+            out["configs"].append(ent)
 
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -231,12 +231,12 @@ def render_all(fonts, name: str, mode: int = PRECISE, threads: int = 1, only_blo
 
 
 def default_threads() -> int:
-    """Worker threads for the CPU legs: the process's CPU affinity, capped at the GPU box's
-    per-GPU CPU share (16) unless VG_CPU_THREADS says otherwise."""
+    """Worker threads for the CPU legs: the CPU affinity of this process (what the box gives this job), no
+    cap; VG_CPU_THREADS overrides."""
     if os.environ.get("VG_CPU_THREADS"):
         return max(1, int(os.environ["VG_CPU_THREADS"]))
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(n, 16))
+    return max(1, n)
 
 
 def sdf_render_batch(batch, mode: int = PRECISE, threads: int = 0):

@@ -61,8 +61,13 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
               "our 8-B-per-lane loads are not separately calibrated)"]
     tj = dst / "traffic.json"
     d = json.loads(tj.read_text()) if tj.exists() else {}
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("sdf_kernels.hip", "sdf_kernels.h"):
+        hsh.update((ROOT / "versatiles-glyphs-rs_amd" / "csrc" / f).read_bytes())
     ent = {"bytes_per_launch": traffic, "fetch_kib": allc["FETCH_SIZE"],
-           "write_kib": allc["WRITE_SIZE"], "profile": f"profiles/{tag}_summary.md"}
+           "write_kib": allc["WRITE_SIZE"], "profile": f"profiles/{tag}_summary.md",
+           "kernel_source_sha256": hsh.hexdigest()}  # bench.py reports these numbers only for the same sources
     main = [r for r in stats if "sdf_tiles" in r["Name"]]
     if main and all(k in allc for k in ("SQ_INSTS_VALU", "SQ_WAVES")):
         # VALU issue rate per SIMD against the measured full-rate issue of gfx950 (tools/ubench/valu_rate.hip:
@@ -72,6 +77,13 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
         ent["valu_insts_per_wave"] = allc["SQ_INSTS_VALU"] / allc["SQ_WAVES"]
         ent["valu_ginst_per_s_per_simd"] = allc["SQ_INSTS_VALU"] / 1024.0 / avg_ns
         ent["valu_issue_frac"] = ent["valu_ginst_per_s_per_simd"] / 0.96
+        ent["kernel_ms"] = avg_ns * 1e-6
+        if "SQ_ACTIVE_INST_VALU" in allc:
+            # SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); 1024 SIMDs; kernel cycles at 2.4 GHz
+            ent["valu_busy_frac"] = allc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avg_ns * 2.4)
+            ent["valu_cycles_per_inst"] = allc["SQ_ACTIVE_INST_VALU"] * 4.0 / allc["SQ_INSTS_VALU"]
+            lines += ["", f"VALU busy: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x {avg_ns:.0f} ns x 2.4 GHz) = "
+                      f"**{ent['valu_busy_frac']:.2f}**; {ent['valu_cycles_per_inst']:.2f} busy cycles per VALU instruction"]
         lines += ["", f"VALU issue: {allc['SQ_INSTS_VALU']:.4g} instructions / 1024 SIMDs / {avg_ns:.0f} ns = "
                   f"**{ent['valu_ginst_per_s_per_simd']:.3f} G inst/s/SIMD** = {ent['valu_issue_frac']:.2f} of the measured "
                   f"full-rate f32 issue (0.96); {ent['valu_insts_per_wave']:.0f} VALU instructions per wave"]
