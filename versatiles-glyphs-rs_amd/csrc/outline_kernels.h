@@ -35,23 +35,38 @@ struct OutlineRect {
 	uint32_t has_raster; // 0 => PbfGlyph::empty (no rings / empty bbox)
 };
 
+// totals of a planned batch, read back by the host together with the rects
+struct PlanHeader {
+	unsigned long long n_segments; // sum of the rasterised glyphs' segments
+	unsigned long long out_bytes;  // sum of w * h
+	uint32_t n_spans;              // entries of the work list (may exceed the capacity it was planned with)
+	uint32_t n_main;               // of which for the main kernel (they come first)
+	uint32_t error;                // != 0: absurd input (a glyph beyond 2^28 points / 2^32 pixels, more than 2^32 - 1 segments)
+	uint32_t pad;
+};
+
+struct GlyphDesc;
+
 } // namespace vgsdf
 
 extern "C" {
-size_t vgsdf_outline_scan_temp_bytes(uint32_t n);
-int vgsdf_outline_scan(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t stream);
-int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, uint32_t n_glyphs, uint8_t *cmd_open,
-                          hipStream_t stream);
-int vgsdf_outline_count(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, uint32_t *counts,
+// cmd_open: one byte per command (bit 0: ring open in front of it, bit 1: the glyph's scale is not positive finite)
+int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
+                          uint8_t *cmd_open, hipStream_t stream);
+// counts: one per command; cmd_box: double4 per command
+int vgsdf_outline_count(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *cmd_off,
+                        uint32_t n_glyphs, const double *scale, const double *shift_x, uint32_t *counts, void *cmd_box,
                         hipStream_t stream);
-int vgsdf_outline_emit(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *pt_off,
-                       double *ptx, double *pty, void *cmd_box /* double4 per command */, hipStream_t stream);
-int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const uint32_t *pt_off, const double *ptx,
-                        const double *pty, const double *scale, const double *shift_x, uint32_t n_glyphs,
-                        vgsdf::RingRec *rings, uint32_t *cmd_ring, vgsdf::OutlineRect *rects, uint32_t *seg_count,
-                        const void *cmd_box, hipStream_t stream);
-int vgsdf_outline_segments(const uint32_t *pt_off, uint32_t n_cmds, uint32_t n_points, const uint32_t *cmd_ring,
-                           const vgsdf::RingRec *rings, const vgsdf::OutlineRect *rects, const uint32_t *seg_off,
-                           const double *ptx, const double *pty, const double *scale, const double *shift_x, double *sx,
-                           double *sy, double *ex, double *ey, hipStream_t stream);
+// pt_local: n_cmds + n_glyphs + 1 entries; error_flag: one zeroed word
+int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const uint8_t *cmd_open, const double *scale,
+                        const double *shift_x, uint32_t n_glyphs, const uint32_t *counts, uint32_t *pt_local, const void *cmd_box,
+                        vgsdf::RingRec *rings, uint32_t *cmd_ring, vgsdf::OutlineRect *rects, uint32_t *error_flag,
+                        hipStream_t stream);
+int vgsdf_outline_plan(const vgsdf::OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
+                       uint32_t span_budget, uint32_t tile_cap, vgsdf::GlyphDesc *descs, uint2 *tiles, vgsdf::PlanHeader *hdr,
+                       const uint32_t *error_flag, hipStream_t stream);
+int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const double *scale, const double *shift_x,
+                                const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,
+                                const vgsdf::GlyphDesc *descs, const vgsdf::PlanHeader *hdr, unsigned long long seg_cap, double *sx,
+                                double *sy, double *ex, double *ey, hipStream_t stream);
 }

@@ -11,18 +11,23 @@
 // units); everything after that is f64 arithmetic replayed here operation by operation
 // (-ffp-contract=off, IEEE divide).
 //
-// Pipeline (one launch each, all tiny next to the SDF raster):
-//   count   thread per command: number of points the command appends to its ring
-//   scan    exclusive prefix sum -> point offsets
-//   emit    thread per command: write the points (font units)
-//   rings   thread per glyph: ring acceptance/closing rules, segment counts, bbox -> rect
-//   scan    exclusive prefix sum of segments per glyph
-//   segs    thread per point: write the scaled + shifted SoA segments
+// Pipeline: five launches, no intermediate point arrays, one read-back (the rects) for the host:
+//   context  wave per glyph: is the ring non-empty in front of every command
+//   count    thread per command: first flattening pass — how many points the command appends, their
+//            bounding box (nothing else is stored)
+//   rings    wave per glyph: point offsets inside the glyph, ring acceptance / closing rules, segment count,
+//            bbox -> rect
+//   plan     one workgroup: segment / output offsets of all glyphs (descriptors), the raster's work list
+//            (spans, heaviest first), totals
+//   emit     thread per command: second flattening pass; every point goes straight into the scaled + shifted
+//            SoA segment arrays as the start of one segment and the end of its predecessor
+// The two flattening passes run one command per thread over the whole batch (balanced whatever the glyph
+// sizes are); a wave-per-glyph form of them measured 2.5x slower (idle lanes, 16 KB of LDS stack per wave).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
 #include "outline_kernels.h"
+#include "sdf_kernels.h"
 
 namespace vgsdf {
 
@@ -165,99 +170,39 @@ __device__ __forceinline__ uint32_t run_command(const OutlineCmd &c, bool ring_o
 	}
 }
 
-// One wave per glyph: is the ring non-empty when command c arrives?  (quad_to / curve_to are
-// ignored on an empty ring, ring_builder.rs:83-85,99-101.)  The ring is empty at the glyph
-// start and after close(); move_to and line_to make it non-empty.  64 commands per step: the
-// state in front of a command is decided by the nearest earlier state-changing command,
-// found with two ballots.
-__global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restrict__ cmds,
-                                                      const uint32_t *__restrict__ cmd_off, uint32_t n_glyphs,
-                                                      uint8_t *__restrict__ cmd_open)
+
+// ring state in front of the 64 commands of one step of a wave: empty at the glyph start and after close();
+// move_to and line_to make it non-empty; decided by the nearest earlier state-changing command (two ballots)
+__device__ __forceinline__ bool ring_open_before(uint32_t kind, uint32_t lane, bool &carry)
 {
-	const uint32_t g = blockIdx.x, lane = threadIdx.x;
-	if (g >= n_glyphs)
-		return;
-	const uint32_t c0 = cmd_off[g], c1 = cmd_off[g + 1];
-	bool carry = false; // ring state in front of the current 64-command window
-	for (uint32_t base = c0; base < c1; base += 64) {
-		const uint32_t c = base + lane;
-		const uint32_t k = c < c1 ? cmds[c].kind : 0xFFu;
-		const unsigned long long opens = __ballot(k == CMD_MOVE || k == CMD_LINE);
-		const unsigned long long closes = __ballot(k == CMD_CLOSE);
-		const unsigned long long before = (opens | closes) & ((1ull << lane) - 1ull);
-		bool open = carry;
-		if (before) {
-			const int top = 63 - __builtin_clzll(before);
-			open = (opens >> top) & 1ull;
-		}
-		if (c < c1)
-			cmd_open[c] = open ? 1 : 0;
-		const unsigned long long all = opens | closes;
-		if (all) {
-			const int top = 63 - __builtin_clzll(all);
-			carry = (opens >> top) & 1ull;
-		}
+	const unsigned long long opens = __ballot(kind == CMD_MOVE || kind == CMD_LINE);
+	const unsigned long long closes = __ballot(kind == CMD_CLOSE);
+	const unsigned long long before = (opens | closes) & ((1ull << lane) - 1ull);
+	bool open = carry;
+	if (before) {
+		const int top = 63 - __builtin_clzll(before);
+		open = (opens >> top) & 1ull;
 	}
-}
-
-// When the ring is open the previous command of the glyph emitted at least one point and
-// ended on its own (x, y): that is the current point of the ring.
-__device__ __forceinline__ void command_context(const OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t i,
-                                                bool &ring_open, double &lastx, double &lasty)
-{
-	ring_open = cmd_open[i] != 0;
-	lastx = ring_open ? (double)cmds[i - 1].x : 0.0;
-	lasty = ring_open ? (double)cmds[i - 1].y : 0.0;
-}
-
-constexpr int kFlattenThreads = 64; // one wave per workgroup: 16 KiB of LDS stack each, 9 workgroups per CU
-
-__global__ __launch_bounds__(kFlattenThreads) void outline_count(const OutlineCmd *__restrict__ cmds,
-                                                                 const uint8_t *__restrict__ cmd_open, uint32_t n_cmds,
-                                                                 uint32_t *__restrict__ counts)
-{
-	__shared__ double s_stack[4 * kLdsLevels * 64];
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n_cmds)
-		return;
-	if (i == n_cmds) { // sentinel so the exclusive scan also yields the total
-		counts[i] = 0;
-		return;
+	const unsigned long long all = opens | closes;
+	if (all) {
+		const int top = 63 - __builtin_clzll(all);
+		carry = (opens >> top) & 1ull;
 	}
-	bool open;
-	double lx, ly;
-	command_context(cmds, cmd_open, i, open, lx, ly);
-	counts[i] = run_command(cmds[i], open, lx, ly, s_stack + threadIdx.x, [](double, double) {});
+	return open;
 }
 
-__global__ __launch_bounds__(kFlattenThreads) void outline_emit(const OutlineCmd *__restrict__ cmds,
-                                                                const uint8_t *__restrict__ cmd_open, uint32_t n_cmds,
-                                                                const uint32_t *__restrict__ pt_off, double *__restrict__ ptx,
-                                                                double *__restrict__ pty, double4 *__restrict__ cmd_box)
+// exclusive prefix sum over the wave (DPP row shifts + row broadcasts); total = sum over all lanes
+__device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t &total)
 {
-	__shared__ double s_stack[4 * kLdsLevels * 64];
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_cmds)
-		return;
-	bool open;
-	double lx, ly;
-	command_context(cmds, cmd_open, i, open, lx, ly);
-	uint32_t k = pt_off[i];
-	// bounding box of the RAW points this command appends (font units): scale > 0 and the shift are
-	// monotone, so the ring pass can take min / max per command and transform four numbers instead of
-	// reading every point again (fmin / fmax skip NaN exactly as they do there)
-	const double inf = __builtin_huge_val();
-	double minx = inf, miny = inf, maxx = -inf, maxy = -inf;
-	run_command(cmds[i], open, lx, ly, s_stack + threadIdx.x, [&](double x, double y) {
-		ptx[k] = x;
-		pty[k] = y;
-		k++;
-		minx = fmin(minx, x);
-		miny = fmin(miny, y);
-		maxx = fmax(maxx, x);
-		maxy = fmax(maxy, y);
-	});
-	cmd_box[i] = make_double4(minx, miny, maxx, maxy);
+	uint32_t incl = v;
+	incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false); // row_shr:1
+	incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false); // row_shr:2
+	incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false); // row_shr:4
+	incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false); // row_shr:8
+	incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+	incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+	total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+	return incl - v;
 }
 
 // Rust `as i32` on f64: truncate, saturate, NaN -> 0
@@ -272,255 +217,229 @@ __device__ __forceinline__ int32_t to_i32(double v)
 	return (int32_t)v;
 }
 
-// One wave per glyph: RingBuilder::save_ring + Ring::close (ring_builder.rs:33-54,
-// ring.rs:53-63), rings.scale / translate / get_bbox and Renderer::prepare_glyph
-// (renderer.rs:122-137, 64-91).  Lane 0 walks the (short) command list and applies the ring
-// rules; all lanes then reduce the bounding box over the accepted rings' points.
-constexpr int kRingCmdsLds = 1024; // commands cached in LDS per glyph (longer lists are read from global)
-constexpr int kRingListLds = 256;  // accepted rings listed in LDS per glyph (more: lane 0 reduces them alone)
 
-__global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict__ cmds, const uint32_t *__restrict__ cmd_off,
-                                                    const uint32_t *__restrict__ pt_off, const double *__restrict__ ptx,
-                                                    const double *__restrict__ pty, const double *__restrict__ scale,
-                                                    const double *__restrict__ shift_x, uint32_t n_glyphs,
-                                                    RingRec *__restrict__ rings, uint32_t *__restrict__ cmd_ring,
-                                                    OutlineRect *__restrict__ rects, uint32_t *__restrict__ seg_count,
-                                                    const double4 *__restrict__ cmd_box)
+// ---------------------------------------------------------------------------------------
+// context: one wave per glyph.  Is the ring non-empty when command c arrives?  (quad_to / curve_to are ignored
+// on an empty ring, ring_builder.rs:83-85,99-101.)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restrict__ cmds, const uint32_t *__restrict__ cmd_off,
+                                                      const double *__restrict__ scale, uint32_t n_glyphs,
+                                                      uint8_t *__restrict__ cmd_open)
 {
-	__shared__ uint8_t s_kind[kRingCmdsLds];
-	__shared__ uint32_t s_poff[kRingCmdsLds + 1];
-	__shared__ uint32_t s_ring_a[kRingListLds], s_ring_n[kRingListLds];
-	__shared__ uint32_t s_nlist, s_nseg, s_nrings;
-	__shared__ double s_box[4];
-
 	const uint32_t g = blockIdx.x, lane = threadIdx.x;
-	if (g == n_glyphs) { // sentinel so the exclusive scan also yields the total
-		if (lane == 0)
-			seg_count[g] = 0;
+	if (g >= n_glyphs)
 		return;
-	}
 	const uint32_t c0 = cmd_off[g], c1 = cmd_off[g + 1];
-	const uint32_t nc = c1 - c0;
-	const bool cached = nc <= (uint32_t)kRingCmdsLds;
-	if (cached) {
-		for (uint32_t i = lane; i < nc; i += 64)
-			s_kind[i] = (uint8_t)cmds[c0 + i].kind;
-		for (uint32_t i = lane; i <= nc; i += 64)
-			s_poff[i] = pt_off[c0 + i];
+	const double sc = scale[g];
+	// bit 1: the glyph's transform is not monotone increasing (scale <= 0 or not finite): the count pass then takes
+	// the bounding boxes on the transformed points
+	const uint8_t odd = (sc > 0.0 && sc < __builtin_huge_val()) ? 0 : 2;
+	bool carry = false;
+	for (uint32_t base = c0; base < c1; base += 64) {
+		const uint32_t c = base + lane;
+		const uint32_t k = c < c1 ? cmds[c].kind : 0xFFu;
+		const bool open = ring_open_before(k, lane, carry);
+		if (c < c1)
+			cmd_open[c] = (uint8_t)((open ? 1 : 0) | odd);
 	}
-	__syncthreads();
-	const double sc = scale[g], dx = shift_x[g];
+}
+
+constexpr int kFlattenThreads = 64; // one wave per workgroup: 16 KiB of LDS stack each, 9 workgroups per CU
+
+// ---------------------------------------------------------------------------------------
+// count: thread per command — the first flattening pass (ring.rs:119-187).  Stores the number of points the
+// command appends and the bounding box of those points: of the raw points when the glyph's transform is
+// monotone (scale > 0: the ring pass transforms four numbers instead of every point), else of the
+// transformed points (point.rs:96-99, 83-86).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kFlattenThreads) void outline_count(const OutlineCmd *__restrict__ cmds,
+                                                                 const uint8_t *__restrict__ cmd_open, uint32_t n_cmds,
+                                                                 const uint32_t *__restrict__ cmd_off, uint32_t n_glyphs,
+                                                                 const double *__restrict__ scale,
+                                                                 const double *__restrict__ shift_x,
+                                                                 uint32_t *__restrict__ counts, double4 *__restrict__ cmd_box)
+{
+	__shared__ double s_stack[4 * kLdsLevels * 64];
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_cmds)
+		return;
+	const OutlineCmd cmd = cmds[i];
+	const uint8_t ctx = cmd_open[i];
+	const bool open = (ctx & 1) != 0;
+	// when the ring is open the previous command of the glyph emitted at least one point and ended on its own
+	// (x, y): that is the current point of the ring
+	const double lx = open ? (double)cmds[i - 1].x : 0.0, ly = open ? (double)cmds[i - 1].y : 0.0;
 	const double inf = __builtin_huge_val();
 	double minx = inf, miny = inf, maxx = -inf, maxy = -inf;
-	auto include = [&](uint32_t i) { // scale, translate, bbox of raw point i
-		double x = ptx[i], y = pty[i];
-		x *= sc; // point.rs:96-99
-		y *= sc;
-		x += dx; // point.rs:83-86
-		y += 0.0;
-		minx = fmin(minx, x); // bbox.rs:64-69
+	const bool raw_boxes = (ctx & 2) == 0;
+	double sc = 1.0, dx = 0.0;
+	if (!raw_boxes) { // rare: find the glyph (last g with cmd_off[g] <= i) for its scale and shift
+		uint32_t lo = 0, hi = n_glyphs;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (cmd_off[mid] <= i)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		sc = scale[lo];
+		dx = shift_x[lo];
+	}
+	counts[i] = run_command(cmd, open, lx, ly, s_stack + threadIdx.x, [&](double x, double y) {
+		if (!raw_boxes) {
+			x *= sc;
+			y *= sc;
+			x += dx;
+			y += 0.0;
+		}
+		minx = fmin(minx, x); // bbox.rs:64-69 (fmin / fmax skip NaN)
 		miny = fmin(miny, y);
 		maxx = fmax(maxx, x);
 		maxy = fmax(maxy, y);
+	});
+	cmd_box[i] = make_double4(minx, miny, maxx, maxy);
+}
+
+// ---------------------------------------------------------------------------------------
+// rings: one wave per glyph, lane <-> command, no serial walk:
+//   pass 1: exclusive sums of the commands' point counts = every command's first point inside the glyph.
+//   pass 2: RingBuilder::save_ring + Ring::close (ring_builder.rs:33-54, ring.rs:53-63).  With `open` = the ring
+//     is non-empty in front of a command (context pass): a command STARTS a ring if it is a move_to, or a
+//     line_to on an empty ring (ring_builder.rs:69-77); it ENDS the ring collected so far if that ring is open
+//     and the command is a move_to or a close (save_ring); the glyph's end saves the last open ring
+//     (into_rings, :26-29).  The lane of the ending command writes the ring's record.  A ring's first point is
+//     the point of the command that opened it and its last point is the end point of its last command (every
+//     command inside an open ring ends on its own (x, y)), so the rules need no stored points.
+//   pass 3: bbox of the accepted rings' points = union of their commands' boxes pushed through the transform
+//     (scale > 0 and the shift are monotone; for any other scale the count pass took the boxes on the
+//     transformed points), then Renderer::prepare_glyph (renderer.rs:64-91, 122-137).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict__ cmds, const uint32_t *__restrict__ cmd_off,
+                                                    const uint8_t *__restrict__ cmd_open, const double *__restrict__ scale,
+                                                    const double *__restrict__ shift_x, uint32_t n_glyphs,
+                                                    const uint32_t *__restrict__ counts, uint32_t *__restrict__ pt_local,
+                                                    const double4 *__restrict__ cmd_box, RingRec *__restrict__ rings,
+                                                    uint32_t *__restrict__ cmd_ring, OutlineRect *__restrict__ rects,
+                                                    uint32_t *__restrict__ error_flag)
+{
+	const uint32_t g = blockIdx.x, lane = threadIdx.x;
+	if (g >= n_glyphs)
+		return;
+	const uint32_t c0 = cmd_off[g], c1 = cmd_off[g + 1];
+	const double sc = scale[g], dx = shift_x[g];
+	const double inf = __builtin_huge_val();
+	const bool raw_boxes = sc > 0.0 && sc < inf; // (the count pass made the same decision)
+
+	// ---- pass 1 ----
+	uint32_t pbase = 0;
+	unsigned long long total64 = 0;
+	for (uint32_t base = c0; base < c1; base += 64) {
+		const uint32_t c = base + lane;
+		const bool valid = c < c1;
+		const uint32_t cnt = valid ? counts[c] : 0u;
+		uint32_t total;
+		const uint32_t excl = wave_exclusive_sum(cnt, total);
+		if (valid)
+			pt_local[c + g] = pbase + excl; // (one slot per command plus one end slot per glyph)
+		pbase += total;
+		total64 += total;
+	}
+	if (lane == 0) {
+		pt_local[c1 + g] = pbase;
+		if (total64 > (1ull << 28)) // (also keeps the 32-bit point offsets of a glyph exact)
+			atomicOr(error_flag, 1u);
+	}
+	__syncthreads(); // pt_local is read back below (other lanes' entries)
+
+	// ---- pass 2 ----
+	auto ring_rec = [&](uint32_t ra, uint32_t rb) {
+		RingRec r;
+		const uint32_t a = pt_local[ra + g], b = pt_local[rb + g]; // points [a, b) of the glyph
+		r.pt_first = a;
+		r.pt_count = b - a;
+		r.append = 0;
+		r.accepted = 0;
+		r.seg_local = 0;
+		r.glyph = g;
+		if (r.pt_count >= 3) { // ring_builder.rs:35-38
+			const double fx = (double)cmds[ra].x, fy = (double)cmds[ra].y, lx = (double)cmds[rb - 1].x, ly = (double)cmds[rb - 1].y;
+			const double eps = 2.220446049250313e-16;
+			r.append = (fabs(fx - lx) > eps || fabs(fy - ly) > eps) ? 1u : 0u; // ring.rs:60-62
+			if (r.pt_count + r.append >= 4)                                      // ring_builder.rs:45-48
+				r.accepted = 1;
+		}
+		return r;
 	};
-
-	// Fast path (command list cached in LDS, at most kRingListLds rings): lane 0 only walks the command
-	// kinds (LDS, no global latency) to cut the list into rings; the per-ring work (first / last point
-	// loads, acceptance, ring record) is then done one ring per lane, segment offsets by a wave scan,
-	// and the per-command ring index is written coalesced.  Everything else: the serial walk below.
-	__shared__ uint32_t s_ra[kRingListLds], s_rb[kRingListLds];
-	__shared__ uint32_t s_cring[kRingCmdsLds];
-	__shared__ uint32_t s_found;
-	__shared__ uint8_t s_accept[kRingCmdsLds]; // per command slot: 1 = this command opened an accepted ring
-	bool fast = cached;
-	if (cached) {
-		if (lane == 0) {
-			uint32_t found = 0;
-			uint32_t ring_start = c0;
-			bool have = false; // a ring is being collected
-			auto cut = [&](uint32_t ra, uint32_t rb) {
-				if (found < (uint32_t)kRingListLds) {
-					s_ra[found] = ra;
-					s_rb[found] = rb;
-				}
-				found++;
-			};
-			for (uint32_t c = c0; c < c1; c++) {
-				const uint32_t k = s_kind[c - c0];
-				if (k == CMD_MOVE) { // move_to: save_ring, then start a new ring with this point
-					if (have)
-						cut(ring_start, c);
-					ring_start = c;
-					have = true;
-				} else if (k == CMD_CLOSE) { // close: save_ring
-					if (have)
-						cut(ring_start, c);
-					have = false;
-					ring_start = c + 1;
-				} else if (!have && k == CMD_LINE) { // line_to on an empty ring starts one (ring_builder.rs:75-77)
-					ring_start = c;
-					have = true;
-				}
-				s_cring[c - c0] = have ? ring_start : 0xFFFFFFFFu;
-			}
-			if (have)
-				cut(ring_start, c1); // into_rings (ring_builder.rs:26-29)
-			s_found = found;
+	uint32_t last_start = 0xFFFFFFFFu; // the command that opened the ring being collected (wave-uniform carry)
+	bool open_after = false;          // ring non-empty behind the last command seen
+	uint32_t seg_base = 0, n_rings_acc = 0;
+	for (uint32_t base = c0; base < c1; base += 64) {
+		const uint32_t c = base + lane;
+		const bool valid = c < c1;
+		const uint32_t k = valid ? cmds[c].kind : 0xFFu;
+		const bool open = valid && (cmd_open[c] & 1);
+		const bool starts = k == CMD_MOVE || (k == CMD_LINE && !open);
+		const bool ends = open && (k == CMD_MOVE || k == CMD_CLOSE);
+		const bool have_after = k == CMD_MOVE || k == CMD_LINE || (valid && k != CMD_CLOSE && open);
+		// nearest ring start at or before this lane (strictly before for the ring this command ends)
+		const unsigned long long sb = __ballot(starts);
+		const unsigned long long below = sb & ((1ull << lane) - 1ull);
+		const uint32_t start_before = below ? base + (uint32_t)(63 - __builtin_clzll(below)) : last_start;
+		const uint32_t start_here = starts ? c : start_before;
+		if (valid)
+			cmd_ring[c] = have_after ? start_here : 0xFFFFFFFFu;
+		RingRec rec;
+		rec.accepted = 0;
+		uint32_t segs = 0;
+		if (ends) {
+			rec = ring_rec(start_before, c);
+			if (rec.accepted)
+				segs = rec.pt_count + rec.append - 1;
 		}
-		__syncthreads();
-		fast = s_found <= (uint32_t)kRingListLds;
+		uint32_t tot_segs, tot_acc;
+		const uint32_t seg_excl = wave_exclusive_sum(segs, tot_segs);
+		(void)wave_exclusive_sum(ends ? rec.accepted : 0u, tot_acc);
+		if (ends) {
+			rec.seg_local = seg_base + seg_excl;
+			rings[start_before] = rec; // ring records live at the index of the command that opened them
+		}
+		seg_base += tot_segs;
+		n_rings_acc += tot_acc;
+		if (sb)
+			last_start = base + (uint32_t)(63 - __builtin_clzll(sb));
+		const unsigned long long ha = __ballot(have_after);
+		const uint32_t n_valid = min(64u, c1 - base);
+		open_after = (ha >> (n_valid - 1)) & 1ull;
 	}
-	const bool boxed = fast && sc > 0.0 && sc < inf; // monotone transform: per-command boxes can be used
-	if (fast) {
-		const uint32_t found = s_found;
-		for (uint32_t i = lane; i < nc; i += 64) {
-			cmd_ring[c0 + i] = s_cring[i];
-			s_accept[i] = 0;
+	if (open_after && lane == 0) { // into_rings: the ring still open at the end of the glyph
+		RingRec rec = ring_rec(last_start, c1);
+		rec.seg_local = seg_base;
+		if (rec.accepted) {
+			seg_base += rec.pt_count + rec.append - 1;
+			n_rings_acc++;
 		}
-		__syncthreads();
-		uint32_t seg_base = 0, n_rings_acc = 0, n_list_acc = 0; // wave-uniform running totals
-		for (uint32_t base = 0; base < found; base += 64) {
-			const uint32_t r = base + lane;
-			const bool valid = r < found;
-			RingRec rec;
-			rec.pt_first = rec.pt_count = rec.append = rec.accepted = rec.seg_local = 0;
-			rec.glyph = g;
-			uint32_t segs = 0, ra = 0;
-			if (valid) {
-				ra = s_ra[r];
-				const uint32_t a = s_poff[ra - c0], bb = s_poff[s_rb[r] - c0]; // raw points [a, bb)
-				const uint32_t n = bb - a;
-				rec.pt_first = a;
-				rec.pt_count = n;
-				if (n >= 3) { // ring_builder.rs:35-38
-					const double fx = ptx[a], fy = pty[a], lx = ptx[bb - 1], ly = pty[bb - 1];
-					const double eps = 2.220446049250313e-16;
-					rec.append = (fabs(fx - lx) > eps || fabs(fy - ly) > eps) ? 1u : 0u; // ring.rs:60-62
-					if (n + rec.append >= 4) { // ring_builder.rs:45-48
-						rec.accepted = 1;
-						segs = n + rec.append - 1;
-					}
-				}
-			}
-			// segment offsets / list slots of the accepted rings, in ring order: inclusive wave scans
-			uint32_t incl = segs, lincl = rec.accepted;
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t o1 = __shfl_up(incl, d), o2 = __shfl_up(lincl, d);
-				if ((int)lane >= d) {
-					incl += o1;
-					lincl += o2;
-				}
-			}
-			if (valid) {
-				rec.seg_local = seg_base + incl - segs;
-				rings[ra] = rec; // ring records live at the index of the command that opened them
-				if (rec.accepted) {
-					const uint32_t slot = n_list_acc + lincl - 1; // < found <= kRingListLds
-					s_ring_a[slot] = rec.pt_first;
-					s_ring_n[slot] = rec.pt_count;
-					s_accept[ra - c0] = 1;
-				}
-			}
-			seg_base += __shfl(incl, 63);
-			const uint32_t acc = __shfl(lincl, 63);
-			n_rings_acc += acc;
-			n_list_acc += acc;
-		}
-		if (lane == 0) {
-			s_nlist = n_list_acc;
-			s_nseg = seg_base;
-			s_nrings = n_rings_acc;
-		}
-		__syncthreads();
-	} else {
-		if (lane == 0) {
-			uint32_t nseg = 0, n_rings = 0, n_list = 0;
-			auto kind_of = [&](uint32_t c) { return cached ? (uint32_t)s_kind[c - c0] : cmds[c].kind; };
-			auto poff_of = [&](uint32_t c) { return cached ? s_poff[c - c0] : pt_off[c]; };
-			// a ring = the points of the commands [ra, rb) that followed its MOVE (or a LINE on an empty ring)
-			auto finish = [&](uint32_t ra, uint32_t rb) {
-				const uint32_t a = poff_of(ra), b = poff_of(rb); // raw points [a, b)
-				RingRec r;
-				r.pt_first = a;
-				r.pt_count = b - a;
-				r.append = 0;
-				r.accepted = 0;
-				r.seg_local = nseg;
-				r.glyph = g;
-				const uint32_t n = b - a;
-				if (n >= 3) { // ring_builder.rs:35-38
-					const double fx = ptx[a], fy = pty[a], lx = ptx[b - 1], ly = pty[b - 1];
-					const double eps = 2.220446049250313e-16;
-					r.append = (fabs(fx - lx) > eps || fabs(fy - ly) > eps) ? 1u : 0u; // ring.rs:60-62
-					if (n + r.append >= 4) { // ring_builder.rs:45-48
-						r.accepted = 1;
-						nseg += n + r.append - 1;
-						n_rings++;
-						if (n_list < (uint32_t)kRingListLds) {
-							s_ring_a[n_list] = a;
-							s_ring_n[n_list] = n;
-							n_list++;
-						} else {
-							for (uint32_t i = a; i < b; i++) // overflow of the list: reduce here
-								include(i);
-						}
-					}
-				}
-				rings[ra] = r; // ring records live at the index of the command that opened them
-			};
-			uint32_t ring_start = c0;
-			bool have = false; // a ring is being collected
-			for (uint32_t c = c0; c < c1; c++) {
-				const uint32_t k = kind_of(c);
-				if (k == CMD_MOVE) { // move_to: save_ring, then start a new ring with this point
-					if (have)
-						finish(ring_start, c);
-					ring_start = c;
-					have = true;
-				} else if (k == CMD_CLOSE) { // close: save_ring
-					if (have)
-						finish(ring_start, c);
-					have = false;
-					ring_start = c + 1;
-				} else if (!have && k == CMD_LINE) { // line_to on an empty ring starts one (ring_builder.rs:75-77)
-					ring_start = c;
-					have = true;
-				}
-				cmd_ring[c] = have ? ring_start : 0xFFFFFFFFu;
-			}
-			if (have)
-				finish(ring_start, c1); // into_rings (ring_builder.rs:26-29)
-			s_nlist = n_list;
-			s_nseg = nseg;
-			s_nrings = n_rings;
-		}
-		__syncthreads();
-
+		rings[last_start] = rec;
 	}
+	seg_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_base);
+	n_rings_acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_rings_acc);
+	__syncthreads(); // cmd_ring / rings are read back below
 
-	// all lanes: bbox over the accepted rings' points (the appended closing point repeats the first)
-	if (boxed) {
-		// per-command boxes of the commands that belong to an accepted ring, then the transform
-		for (uint32_t i = lane; i < nc; i += 64) {
-			const uint32_t rs = s_cring[i];
-			if (rs != 0xFFFFFFFFu && s_accept[rs - c0]) {
-				const double4 bx = cmd_box[c0 + i];
-				minx = fmin(minx, bx.x);
-				miny = fmin(miny, bx.y);
-				maxx = fmax(maxx, bx.z);
-				maxy = fmax(maxy, bx.w);
-			}
+	// ---- pass 3 ----
+	double minx = inf, miny = inf, maxx = -inf, maxy = -inf;
+	for (uint32_t c = c0 + lane; c < c1; c += 64) {
+		const uint32_t rs = cmd_ring[c];
+		if (rs != 0xFFFFFFFFu && rings[rs].accepted) {
+			const double4 bx = cmd_box[c];
+			minx = fmin(minx, bx.x);
+			miny = fmin(miny, bx.y);
+			maxx = fmax(maxx, bx.z);
+			maxy = fmax(maxy, bx.w);
 		}
+	}
+	if (raw_boxes) {
 		minx *= sc, miny *= sc, maxx *= sc, maxy *= sc; // point.rs:96-99
 		minx += dx, maxx += dx;                         // point.rs:83-86
 		miny += 0.0, maxy += 0.0;
-	} else {
-		const uint32_t n_list = s_nlist;
-		for (uint32_t r = 0; r < n_list; r++) {
-			const uint32_t a = s_ring_a[r], n = s_ring_n[r];
-			for (uint32_t i = lane; i < n; i += 64)
-				include(a + i);
-		}
 	}
 	for (int sh = 32; sh > 0; sh >>= 1) { // fmin/fmax are exact selections: any order gives the same box
 		minx = fmin(minx, __shfl_xor(minx, sh));
@@ -529,7 +448,7 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 		maxy = fmax(maxy, __shfl_xor(maxy, sh));
 	}
 	if (lane == 0) {
-		const uint32_t nseg = s_nseg, n_rings = s_nrings;
+		const uint32_t nseg = seg_base, n_rings = n_rings_acc;
 		OutlineRect rc;
 		rc.x0 = rc.y0 = 0;
 		rc.w = rc.h = 0;
@@ -547,126 +466,299 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 			rc.has_raster = 1;
 		}
 		rects[g] = rc;
-		seg_count[g] = rc.has_raster ? nseg : 0;
 	}
-	(void)s_box;
 }
 
-// Thread per raw point: Rings::get_segments (rings.rs:75-81) after scale + translate.
-__global__ void outline_segments(const uint32_t *__restrict__ pt_off, uint32_t n_cmds, uint32_t n_points,
-                                 const uint32_t *__restrict__ cmd_ring, const RingRec *__restrict__ rings,
-                                 const OutlineRect *__restrict__ rects, const uint32_t *__restrict__ seg_off,
-                                 const double *__restrict__ ptx, const double *__restrict__ pty,
-                                 const double *__restrict__ scale, const double *__restrict__ shift_x,
-                                 double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ ex,
-                                 double *__restrict__ ey)
+// ---------------------------------------------------------------------------------------
+// plan: ONE workgroup.  From the rects: the glyph descriptors (segment and output offsets: exclusive sums),
+// the raster's work list and the totals the host reads back together with the rects.  The list follows the
+// host's policy for resident batches (vgsdf_device.cpp, build_descs_and_tiles): class (main kernel / brute
+// force), span length T per glyph, heaviest workgroup first (counting sort over 512 logarithmic weight
+// buckets; the order inside a bucket is whatever the atomics give: it only shapes the schedule).
+// ---------------------------------------------------------------------------------------
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanBuckets = 512;
+
+__device__ __forceinline__ uint32_t plan_bucket(uint32_t wgt) // bucket 0 = heaviest
 {
-	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= n_points)
-		return;
-	// command that emitted point p: last c with pt_off[c] <= p (pt_off has n_cmds + 1 entries)
-	uint32_t lo = 0, hi = n_cmds;
-	while (hi - lo > 1) {
-		const uint32_t mid = (lo + hi) >> 1;
-		if (pt_off[mid] <= p)
-			lo = mid;
-		else
-			hi = mid;
+	if (wgt < 16u)
+		return 511u - wgt;
+	const uint32_t e = 31u - (uint32_t)__builtin_clz(wgt);      // 4..31
+	return 511u - ((e - 3u) * 16u + ((wgt >> (e - 4u)) & 15u)); // 16..463 -> descending
+}
+
+// block-wide exclusive sum of one value per thread (1024 threads = 16 waves); returns the exclusive prefix, sets total
+__device__ __forceinline__ unsigned long long block_exclusive_sum(unsigned long long v, unsigned long long *s_wave /*[17]*/,
+                                                                  unsigned long long &total)
+{
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned long long incl = v;
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned long long o = __shfl_up(incl, d);
+		if ((int)lane >= d)
+			incl += o;
 	}
-	const uint32_t rcmd = cmd_ring[lo];
+	__syncthreads(); // s_wave free again
+	if (lane == 63)
+		s_wave[wv] = incl;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long acc = 0;
+		for (int w = 0; w < kPlanThreads / 64; w++) {
+			const unsigned long long t = s_wave[w];
+			s_wave[w] = acc;
+			acc += t;
+		}
+		s_wave[kPlanThreads / 64] = acc;
+	}
+	__syncthreads();
+	total = s_wave[kPlanThreads / 64];
+	return s_wave[wv] + incl - v;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *__restrict__ rects, uint32_t n_glyphs, int span_list,
+                                                             uint32_t delta_cap, uint32_t span_max, uint32_t span_budget,
+                                                             uint32_t tile_cap, GlyphDesc *__restrict__ descs,
+                                                             uint2 *__restrict__ tiles, PlanHeader *__restrict__ hdr,
+                                                             const uint32_t *__restrict__ error_flag)
+{
+	__shared__ unsigned long long s_wave[kPlanThreads / 64 + 1];
+	__shared__ uint32_t s_hist[2][kPlanBuckets]; // spans per (class, bucket); then the bucket's write cursor
+	__shared__ unsigned long long s_carry[2];
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t i = tid; i < 2 * kPlanBuckets; i += kPlanThreads)
+		(&s_hist[0][0])[i] = 0;
+	if (tid == 0)
+		s_carry[0] = s_carry[1] = 0;
+	__syncthreads();
+	// rows touched by T consecutive tiles, times the (odd-padded) row stride, must fit the winding histogram
+	auto fits = [&](uint32_t w, uint32_t T) { return (unsigned long long)((256u * T - 2u) / w + 2u) * ((unsigned long long)w + 2u) <= delta_cap; };
+	// class (0 main / 1 brute), span length and span count of a glyph
+	auto classify = [&](const OutlineRect &r, uint32_t &cls, uint32_t &T, uint32_t &nspans, uint32_t &weight) {
+		const unsigned long long px = r.has_raster ? (unsigned long long)r.w * r.h : 0ull;
+		cls = 0, T = 1, nspans = 0, weight = 0;
+		if (px == 0)
+			return;
+		const uint32_t nseg = r.n_segments;
+		if (!fits(r.w, 1) || nseg >= (1u << 24)) {
+			cls = 1;
+		} else if (span_list) {
+			const uint32_t chunks = (nseg + 255u) / 256u;
+			const uint32_t t_hi = min(span_max, max(1u, span_budget / max(chunks, 1u)));
+			for (T = t_hi; T > 1; T--)
+				if (fits(r.w, T))
+					break;
+		}
+		const unsigned long long t256 = (px + 255ull) >> 8;
+		nspans = (uint32_t)((t256 + T - 1) / T);
+		const unsigned long long wgt = (unsigned long long)nseg * (t256 < T ? t256 : T);
+		weight = wgt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wgt;
+	};
+	// pass A: descriptors (exclusive sums of segments and output bytes), span histogram.  Every thread takes a
+	// contiguous run of glyphs: one block-wide scan of the runs' sums, then a running sum inside the run.
+	bool bad = false;
+	const uint32_t per = (n_glyphs + kPlanThreads - 1) / kPlanThreads;
+	const uint32_t g_lo = min(tid * per, n_glyphs), g_hi = min(g_lo + per, n_glyphs);
+	{
+		unsigned long long my_s = 0, my_p = 0;
+		for (uint32_t g = g_lo; g < g_hi; g++) {
+			const OutlineRect r = rects[g];
+			if (r.has_raster) {
+				my_s += r.n_segments;
+				my_p += (unsigned long long)r.w * r.h;
+				bad |= (unsigned long long)r.w * r.h > 0xFFFFFFFFull - 256ull;
+			}
+		}
+		unsigned long long tot_s, tot_p;
+		unsigned long long so = block_exclusive_sum(my_s, s_wave, tot_s);
+		unsigned long long po = block_exclusive_sum(my_p, s_wave, tot_p);
+		if (tid == 0) {
+			s_carry[0] = tot_s;
+			s_carry[1] = tot_p;
+		}
+		for (uint32_t g = g_lo; g < g_hi; g++) {
+			const OutlineRect r = rects[g];
+			const unsigned long long px = r.has_raster ? (unsigned long long)r.w * r.h : 0ull;
+			const unsigned long long segs = r.has_raster ? r.n_segments : 0u;
+			GlyphDesc d;
+			d.seg_off = (uint32_t)so; // (the host rejects batches with more than 2^32 - 1 segments: header)
+			d.n_seg = (uint32_t)segs;
+			d.x0 = r.x0;
+			d.y0 = r.y0;
+			d.w = r.has_raster ? r.w : 0;
+			d.h = r.has_raster ? r.h : 0;
+			d.out_off = po;
+			descs[g] = d;
+			so += segs;
+			po += px;
+			uint32_t cls, T, nspans, weight;
+			classify(r, cls, T, nspans, weight);
+			if (nspans)
+				atomicAdd(&s_hist[cls][plan_bucket(weight)], nspans);
+		}
+	}
+	__syncthreads();
+	// bucket bases: main class first (heaviest bucket first), then the brute-force class — one (class, bucket)
+	// cell per thread
+	__shared__ uint32_t s_nmain, s_nall;
+	static_assert(2 * kPlanBuckets == kPlanThreads, "one histogram cell per thread");
+	{
+		const unsigned long long mine = (&s_hist[0][0])[tid];
+		unsigned long long acc;
+		const unsigned long long base_at = block_exclusive_sum(mine, s_wave, acc);
+		(&s_hist[0][0])[tid] = (uint32_t)(base_at > 0xFFFFFFFFull ? 0xFFFFFFFFull : base_at);
+		if (tid == kPlanBuckets) // first cell of the brute-force class: everything before it is main class
+			s_nmain = (uint32_t)(base_at > 0x7FFFFFFFull ? 0x7FFFFFFFull : base_at);
+		if (tid == 0)
+			s_nall = (uint32_t)(acc > 0x7FFFFFFFull ? 0x80000000ull : acc);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		const unsigned long long acc = s_nall;
+		hdr->n_segments = s_carry[0];
+		hdr->out_bytes = s_carry[1];
+		hdr->n_spans = s_nall;
+		hdr->n_main = s_nmain;
+		hdr->error = (error_flag[0] != 0) || (s_carry[0] > 0xFFFFFFFFull) || (acc > 0x7FFFFFFFull);
+		hdr->pad = 0;
+	}
+	__syncthreads();
+	const bool any_bad = __syncthreads_or(bad);
+	if (tid == 0 && any_bad)
+		hdr->error = 1;
+	if (s_nall > tile_cap) // the host grows the list and runs the plan again
+		return;
+	// pass B: entries.  One per span of T tiles: (glyph, first pixel | T) in the span list's main class, else
+	// (glyph, first pixel).
+	for (uint32_t g = tid; g < n_glyphs; g += kPlanThreads) {
+		const OutlineRect r = rects[g];
+		uint32_t cls, T, nspans, weight;
+		classify(r, cls, T, nspans, weight);
+		if (!nspans)
+			continue;
+		uint32_t at = atomicAdd(&s_hist[cls][plan_bucket(weight)], nspans);
+		const unsigned long long px = (unsigned long long)r.w * r.h;
+		for (unsigned long long p = 0; p < px; p += 256ull * T) {
+			const uint32_t left = (uint32_t)((px - p + 255ull) >> 8);
+			tiles[at++] = make_uint2(g, span_list && cls == 0 ? ((uint32_t)p | min(T, left)) : (uint32_t)p);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// emit: thread per command — the second flattening pass.  Point i of a ring of n points is the start of segment i
+// (i <= n - 2, or i == n - 1 when Ring::close appended the first point again) and the end of segment i - 1; with
+// the appended point, point 0 also ends segment n - 1 (Rings::get_segments, rings.rs:75-81) — written straight
+// into the SoA arrays after scale + translate (renderer.rs:122-131).  A command that belongs to a ring has the
+// ring open in front of it unless it opened the ring itself (move_to / line_to, which do not care).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const OutlineCmd *__restrict__ cmds, uint32_t n_cmds,
+                                                                         const double *__restrict__ scale,
+                                                                         const double *__restrict__ shift_x,
+                                                                         const uint32_t *__restrict__ pt_local,
+                                                                         const RingRec *__restrict__ rings,
+                                                                         const uint32_t *__restrict__ cmd_ring,
+                                                                         const GlyphDesc *__restrict__ descs,
+                                                                         const PlanHeader *__restrict__ hdr,
+                                                                         unsigned long long seg_cap, double *__restrict__ sx,
+                                                                         double *__restrict__ sy, double *__restrict__ ex,
+                                                                         double *__restrict__ ey)
+{
+	__shared__ double s_stack[4 * kLdsLevels * 64];
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cmds)
+		return;
+	if (hdr->error || hdr->n_segments > seg_cap) // nothing may be written: the host grows the arrays and launches again
+		return;
+	const uint32_t rcmd = cmd_ring[c];
 	if (rcmd == 0xFFFFFFFFu)
 		return;
 	const RingRec r = rings[rcmd];
-	if (!r.accepted || !rects[r.glyph].has_raster)
+	if (!r.accepted)
 		return;
-	const uint32_t idx = p - r.pt_first; // position inside the ring
-	uint32_t q;                          // the segment's end point
-	if (idx + 1 < r.pt_count)
-		q = p + 1;
-	else if (r.append)
-		q = r.pt_first; // closing segment back to the first point
-	else
-		return; // last point of a ring that was already closed
+	const GlyphDesc d = descs[r.glyph];
+	if (d.n_seg == 0) // PbfGlyph::empty (empty bbox): nothing is rasterised
+		return;
+	const OutlineCmd cmd = cmds[c];
+	const bool open = c != rcmd;
+	const double lx = open ? (double)cmds[c - 1].x : 0.0, ly = open ? (double)cmds[c - 1].y : 0.0;
 	const double sc = scale[r.glyph], dx = shift_x[r.glyph];
-	double ax = ptx[p], ay = pty[p], bx = ptx[q], by = pty[q];
-	ax *= sc;
-	ay *= sc;
-	bx *= sc;
-	by *= sc;
-	ax += dx;
-	ay += 0.0;
-	bx += dx;
-	by += 0.0;
-	const uint32_t s = seg_off[r.glyph] + r.seg_local + idx;
-	sx[s] = ax;
-	sy[s] = ay;
-	ex[s] = bx;
-	ey[s] = by;
+	uint32_t idx = pt_local[c + r.glyph] - r.pt_first; // position of the command's first point inside its ring
+	const size_t seg0 = (size_t)d.seg_off + r.seg_local;
+	const uint32_t n = r.pt_count, last_seg = n - 1; // segment n - 1 exists only with the appended point
+	run_command(cmd, open, lx, ly, s_stack + threadIdx.x, [&](double x, double y) {
+		x *= sc; // point.rs:96-99
+		y *= sc;
+		x += dx; // point.rs:83-86
+		y += 0.0;
+		if (idx + 1 < n || r.append) { // start of segment idx
+			sx[seg0 + idx] = x;
+			sy[seg0 + idx] = y;
+		}
+		if (idx >= 1) { // end of segment idx - 1
+			ex[seg0 + idx - 1] = x;
+			ey[seg0 + idx - 1] = y;
+		} else if (r.append) { // the closing segment returns to the first point
+			ex[seg0 + last_seg] = x;
+			ey[seg0 + last_seg] = y;
+		}
+		idx++;
+	});
 }
 
 } // namespace vgsdf
 
 using namespace vgsdf;
 
-extern "C" size_t vgsdf_outline_scan_temp_bytes(uint32_t n)
-{
-	size_t bytes = 0;
-	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-	return bytes;
-}
-
-extern "C" int vgsdf_outline_scan(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, uint32_t n,
-                                  hipStream_t stream)
-{
-	return (int)hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, stream);
-}
-
-extern "C" int vgsdf_outline_context(const OutlineCmd *cmds, const uint32_t *cmd_off, uint32_t n_glyphs, uint8_t *cmd_open,
-                                     hipStream_t stream)
+extern "C" int vgsdf_outline_context(const OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
+                                     uint8_t *cmd_open, hipStream_t stream)
 {
 	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(outline_context, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, n_glyphs, cmd_open);
+	hipLaunchKernelGGL(outline_context, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, scale, n_glyphs, cmd_open);
 	return (int)hipGetLastError();
 }
 
-// counts has n_cmds + 1 entries (the last one is a 0 sentinel)
-extern "C" int vgsdf_outline_count(const OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, uint32_t *counts,
+extern "C" int vgsdf_outline_count(const OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *cmd_off,
+                                   uint32_t n_glyphs, const double *scale, const double *shift_x, uint32_t *counts, void *cmd_box,
                                    hipStream_t stream)
-{
-	hipLaunchKernelGGL(outline_count, dim3((n_cmds + 1 + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream, cmds, cmd_open, n_cmds, counts);
-	return (int)hipGetLastError();
-}
-
-extern "C" int vgsdf_outline_emit(const OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *pt_off,
-                                  double *ptx, double *pty, void *cmd_box, hipStream_t stream)
 {
 	if (n_cmds == 0)
 		return 0;
-	hipLaunchKernelGGL(outline_emit, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream,
-	                   cmds, cmd_open, n_cmds, pt_off, ptx, pty, (double4 *)cmd_box);
+	hipLaunchKernelGGL(outline_count, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream, cmds,
+	                   cmd_open, n_cmds, cmd_off, n_glyphs, scale, shift_x, counts, (double4 *)cmd_box);
 	return (int)hipGetLastError();
 }
 
-extern "C" int vgsdf_outline_rings(const OutlineCmd *cmds, const uint32_t *cmd_off, const uint32_t *pt_off, const double *ptx,
-                                   const double *pty, const double *scale, const double *shift_x, uint32_t n_glyphs,
-                                   RingRec *rings, uint32_t *cmd_ring, OutlineRect *rects, uint32_t *seg_count,
-                                   const void *cmd_box, hipStream_t stream)
+extern "C" int vgsdf_outline_rings(const OutlineCmd *cmds, const uint32_t *cmd_off, const uint8_t *cmd_open, const double *scale,
+                                   const double *shift_x, uint32_t n_glyphs, const uint32_t *counts, uint32_t *pt_local,
+                                   const void *cmd_box, RingRec *rings, uint32_t *cmd_ring, OutlineRect *rects,
+                                   uint32_t *error_flag, hipStream_t stream)
 {
-	// one wave per glyph; seg_count has n_glyphs + 1 entries (the last one is a 0 sentinel)
-	hipLaunchKernelGGL(outline_rings, dim3(n_glyphs + 1), dim3(64), 0, stream, cmds, cmd_off, pt_off, ptx, pty, scale,
-	                   shift_x, n_glyphs, rings, cmd_ring, rects, seg_count, (const double4 *)cmd_box);
-	return (int)hipGetLastError();
-}
-
-extern "C" int vgsdf_outline_segments(const uint32_t *pt_off, uint32_t n_cmds, uint32_t n_points, const uint32_t *cmd_ring,
-                                      const RingRec *rings, const OutlineRect *rects, const uint32_t *seg_off,
-                                      const double *ptx, const double *pty, const double *scale, const double *shift_x,
-                                      double *sx, double *sy, double *ex, double *ey, hipStream_t stream)
-{
-	if (n_points == 0)
+	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(outline_segments, dim3((n_points + 255) / 256), dim3(256), 0, stream, pt_off, n_cmds, n_points, cmd_ring,
-	                   rings, rects, seg_off, ptx, pty, scale, shift_x, sx, sy, ex, ey);
+	hipLaunchKernelGGL(outline_rings, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, cmd_open, scale, shift_x, n_glyphs, counts, pt_local,
+	                   (const double4 *)cmd_box, rings, cmd_ring, rects, error_flag);
+	return (int)hipGetLastError();
+}
+
+extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
+                                  uint32_t span_budget, uint32_t tile_cap, GlyphDesc *descs, uint2 *tiles, PlanHeader *hdr,
+                                  const uint32_t *error_flag, hipStream_t stream)
+{
+	hipLaunchKernelGGL(outline_plan, dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
+	                   span_budget, tile_cap, descs, tiles, hdr, error_flag);
+	return (int)hipGetLastError();
+}
+
+extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cmds, const double *scale, const double *shift_x,
+                                           const uint32_t *pt_local, const RingRec *rings, const uint32_t *cmd_ring,
+                                           const GlyphDesc *descs, const PlanHeader *hdr, unsigned long long seg_cap, double *sx,
+                                           double *sy, double *ex, double *ey, hipStream_t stream)
+{
+	if (n_cmds == 0)
+		return 0;
+	hipLaunchKernelGGL(outline_emit_segments, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream,
+	                   cmds, n_cmds, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, sx, sy, ex, ey);
 	return (int)hipGetLastError();
 }

@@ -206,7 +206,7 @@ __device__ __forceinline__ uint32_t chunk_box_index(uint32_t seg_off, uint32_t g
 	return (seg_off >> 8) + glyph + c;
 }
 
-__global__ __launch_bounds__(64) void sdf_chunk_boxes(const GlyphDesc *__restrict__ glyphs, uint32_t n_glyphs,
+__global__ __launch_bounds__(256) void sdf_chunk_boxes(const GlyphDesc *__restrict__ glyphs, uint32_t n_glyphs,
                                                       const double *__restrict__ seg_sx,
                                                       const double *__restrict__ seg_sy,
                                                       const double *__restrict__ seg_ex,
@@ -214,10 +214,13 @@ __global__ __launch_bounds__(64) void sdf_chunk_boxes(const GlyphDesc *__restric
 {
 	// grid = (glyphs, CHUNK_BOX_Y): chunk c of a glyph is taken by the wave with blockIdx.y == c % gridDim.y, so
 	// the 18 chunks of a long glyph are not walked one after the other by a single wave
-	const uint32_t gi = blockIdx.x, lane = threadIdx.x;
+	// one wave per (glyph, chunk mod gridDim.y); four glyphs per workgroup (fewer, larger workgroups to dispatch)
+	const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (gi >= n_glyphs)
 		return;
 	const GlyphDesc g = glyphs[gi];
+	if (g.n_seg <= 2 * FCHUNK) // the span kernel asks for boxes only when a glyph has more than two chunks
+		return;
 	for (uint32_t c = blockIdx.y; (uint64_t)c * FCHUNK < g.n_seg; c += gridDim.y) {
 		const uint32_t c0 = c * FCHUNK;
 		const uint32_t cnt = min((uint32_t)FCHUNK, g.n_seg - c0);
@@ -835,7 +838,7 @@ extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t
 {
 	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3(n_glyphs, 4), dim3(64), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
+	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3((n_glyphs + 3) / 4, 4), dim3(256), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
 	                   (float4 *)boxes);
 	return (int)hipGetLastError();
 }

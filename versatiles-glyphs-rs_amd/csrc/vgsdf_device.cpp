@@ -102,10 +102,12 @@ struct DevBuf {
 };
 
 struct FrontEnd {
-	DevBuf cmds, meta, cmd_box, cmd_open, counts, pt_off, ptx, pty, rings, cmd_ring, rects, seg_count, seg_off, scan_tmp;
-	DevBuf sx, sy, ex, ey, descs_tiles, out, boxes;
+	// device: inputs, per-command / per-ring intermediates, results of measure + plan, the resident batch
+	DevBuf cmds, meta, cmd_open, counts, pt_local, cmd_box, rings, cmd_ring, rects_hdr, descs, tiles, flag;
+	DevBuf sx, sy, ex, ey, out, boxes;
 	DevBuf h_rects, h_stage; // pinned
-	uint32_t n_glyphs = 0, n_cmds = 0, n_points = 0, n_segs = 0;
+	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
+	uint32_t n_glyphs = 0, n_cmds = 0, n_segs = 0;
 	uint64_t out_bytes = 0;
 	vgsdf_dbatch batch; // borrowed view over the buffers above
 	bool prepared = false;
@@ -117,8 +119,8 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &meta, &cmd_box, &cmd_open, &counts, &pt_off, &ptx, &pty, &rings, &cmd_ring, &rects,
-		                  &seg_count, &seg_off, &scan_tmp, &sx, &sy, &ex, &ey, &descs_tiles, &out, &boxes, &h_rects, &h_stage})
+		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &sx, &sy, &ex, &ey,
+		                  &out, &boxes, &h_rects, &h_stage})
 			b->release();
 	}
 };
@@ -777,7 +779,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	fe.prepared = false;
 	fe.n_glyphs = n;
 	fe.n_cmds = n_cmds;
-	fe.n_points = fe.n_segs = 0;
+	fe.n_segs = 0;
 	fe.out_bytes = 0;
 	if (out_bytes)
 		*out_bytes = 0;
@@ -790,23 +792,47 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	}
 	tr1 = fe_now();
 	hipStream_t st = ctx->stream;
+	const bool span = ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 69);
 	FE_TRY(fe.cmds.ensure(sizeof(vgsdf::OutlineCmd) * (size_t)(n_cmds + 1)));
 	// per-glyph inputs (scale, shift, command offsets) travel as ONE block through pinned staging
 	const size_t meta_scale = 0, meta_shift = 8 * (size_t)n, meta_off = 16 * (size_t)n, meta_bytes = meta_off + 4 * (size_t)(n + 1);
 	FE_TRY(fe.meta.ensure(meta_bytes + 16));
 	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
-	FE_TRY(fe.cmd_box.ensure(32 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
-	FE_TRY(fe.pt_off.ensure(4 * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.pt_local.ensure(4 * ((size_t)n_cmds + n + 2)));
+	FE_TRY(fe.cmd_box.ensure(32 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.rings.ensure(sizeof(vgsdf::RingRec) * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.cmd_ring.ensure(4 * (size_t)(n_cmds + 1)));
-	FE_TRY(fe.rects.ensure(sizeof(vgsdf::OutlineRect) * (size_t)n));
-	FE_TRY(fe.seg_count.ensure(4 * (size_t)(n + 1)));
-	FE_TRY(fe.seg_off.ensure(4 * (size_t)(n + 1)));
-	const size_t tmp = std::max(vgsdf_outline_scan_temp_bytes(n_cmds + 1), vgsdf_outline_scan_temp_bytes(n + 1));
-	FE_TRY(fe.scan_tmp.ensure(tmp));
-	FE_TRY(fe.h_rects.ensure(sizeof(vgsdf::OutlineRect) * (size_t)n + 16));
+	const size_t hdr_off = align_up(sizeof(vgsdf::OutlineRect) * (size_t)n, 16); // rects and totals: one block, one read-back
+	const size_t rh_bytes = hdr_off + sizeof(vgsdf::PlanHeader);
+	FE_TRY(fe.rects_hdr.ensure(rh_bytes));
+	FE_TRY(fe.h_rects.ensure(rh_bytes));
+	FE_TRY(fe.descs.ensure(sizeof(vgsdf::GlyphDesc) * (size_t)n + 16));
+	FE_TRY(fe.flag.ensure(16));
+	// capacities of what only the device knows the size of: the work list and the segment arrays.  Guessed from
+	// the input (and kept from earlier batches); the plan / emit kernels write nothing past them and the totals
+	// that come back with the rects say whether a second launch is needed.
+	auto ensure_tiles = [&](size_t want) -> hipError_t {
+		if (want <= fe.tile_cap)
+			return hipSuccess;
+		hipError_t e = fe.tiles.ensure(sizeof(uint2) * want);
+		if (e == hipSuccess)
+			fe.tile_cap = fe.tiles.cap / sizeof(uint2);
+		return e;
+	};
+	auto ensure_segs = [&](size_t want) -> hipError_t {
+		if (want <= fe.seg_cap)
+			return hipSuccess;
+		for (DevBuf *b : {&fe.sx, &fe.sy, &fe.ex, &fe.ey})
+			if (hipError_t e = b->ensure(8 * want + 8); e != hipSuccess)
+				return e;
+		fe.seg_cap = std::min({fe.sx.cap, fe.sy.cap, fe.ex.cap, fe.ey.cap}) / 8 - 1;
+		return fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.seg_cap, n) + 16);
+	};
+	FE_TRY(ensure_tiles(2 * (size_t)n + 1024));
+	FE_TRY(ensure_segs(12 * (size_t)n_cmds + 4096));
+	FE_TRY(fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.seg_cap, n) + 16));
 
 	if (n_cmds)
 		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
@@ -817,140 +843,117 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		std::memcpy(hm + meta_off, in->cmd_off, 4 * (size_t)(n + 1));
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
 	}
+	FE_TRY(hipMemsetAsync(fe.flag.p, 0, 16, st));
 	const double *d_scale = (const double *)((const uint8_t *)fe.meta.p + meta_scale);
 	const double *d_shift = (const double *)((const uint8_t *)fe.meta.p + meta_shift);
 	const uint32_t *d_cmd_off = (const uint32_t *)((const uint8_t *)fe.meta.p + meta_off);
-
 	auto *d_cmds = (const vgsdf::OutlineCmd *)fe.cmds.p;
-	FE_KERNEL(vgsdf_outline_context(d_cmds, d_cmd_off, n, (uint8_t *)fe.cmd_open.p, st));
-	FE_KERNEL(vgsdf_outline_count(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (uint32_t *)fe.counts.p, st));
-	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_off.p,
-	                             n_cmds + 1, st));
-	uint32_t *h_word = (uint32_t *)fe.h_rects.p; // pinned scratch for the read-backs
-	FE_TRY(hipMemcpyAsync(h_word, (const uint32_t *)fe.pt_off.p + n_cmds, 4, hipMemcpyDeviceToHost, st));
+	auto *d_rects = (vgsdf::OutlineRect *)fe.rects_hdr.p;
+	auto *d_hdr = (vgsdf::PlanHeader *)((uint8_t *)fe.rects_hdr.p + hdr_off);
+	auto *d_descs = (vgsdf::GlyphDesc *)fe.descs.p;
+
+	// span policy of the work list (same switches as build_descs_and_tiles)
+	const char *sm = std::getenv("VGSDF_SPAN_MAX");
+	const uint32_t span_max = sm ? (uint32_t)std::min(4, std::max(1, std::atoi(sm))) : 4u;
+	const char *sb = std::getenv("VGSDF_SPAN_BUDGET");
+	const uint32_t span_budget = sb ? (uint32_t)std::max(1, std::atoi(sb)) : 16u;
+	auto launch_plan = [&]() {
+		return vgsdf_outline_plan(d_rects, n, span ? 1 : 0, (uint32_t)vgsdf_filtered_delta_cap(), span_max, span_budget,
+		                          (uint32_t)std::min<size_t>(fe.tile_cap, 0x7FFFFFFFu), d_descs, (uint2 *)fe.tiles.p, d_hdr,
+		                          (const uint32_t *)fe.flag.p, st);
+	};
+	auto launch_emit = [&]() -> int {
+		int e = vgsdf_outline_emit_segments(d_cmds, n_cmds, d_scale, d_shift, (const uint32_t *)fe.pt_local.p,
+		                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d_descs, d_hdr,
+		                                    (unsigned long long)fe.seg_cap, (double *)fe.sx.p, (double *)fe.sy.p, (double *)fe.ex.p,
+		                                    (double *)fe.ey.p, st);
+		if (e == 0 && span)
+			e = vgsdf_launch_chunk_boxes(d_descs, n, (const double *)fe.sx.p, (const double *)fe.sy.p, (const double *)fe.ex.p,
+			                             (const double *)fe.ey.p, fe.boxes.p, st);
+		return e;
+	};
+	FE_KERNEL(vgsdf_outline_context(d_cmds, d_cmd_off, d_scale, n, (uint8_t *)fe.cmd_open.p, st));
+	FE_KERNEL(vgsdf_outline_count(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, d_cmd_off, n, d_scale, d_shift,
+	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, st));
+	FE_KERNEL(vgsdf_outline_rings(d_cmds, d_cmd_off, (const uint8_t *)fe.cmd_open.p, d_scale, d_shift, n,
+	                              (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_local.p,
+	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d_rects,
+	                              (uint32_t *)fe.flag.p, st));
+	FE_KERNEL(launch_plan());
+	FE_KERNEL(launch_emit());
+	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, rh_bytes, hipMemcpyDeviceToHost, st));
+	// (the command kinds are checked here, while the GPU works: the kernels treat an unknown kind as a no-op,
+	// so nothing unsafe runs before the check)
 	bool kinds_ok = true;
 	for (uint32_t c = 0; c < n_cmds; c++)
 		kinds_ok &= in->cmds[c].kind <= 4u;
-	FE_TRY(hipStreamSynchronize(st));
+	FE_TRY(hipStreamSynchronize(st)); // the one read-back of the front-end
 	if (!kinds_ok) {
 		ctx->err = "vgsdf_outlines_prepare: unknown command kind";
 		return VGSDF_E_ARG;
 	}
 	tr2 = fe_now();
-	const uint32_t n_points = h_word[0];
-	fe.n_points = n_points;
-	if (n_points > (1u << 28)) {
-		ctx->err = "vgsdf_outlines_prepare: outlines flatten to more than 2^28 points (non-finite or absurd control points?)";
+	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
+	vgsdf::PlanHeader hdr;
+	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + hdr_off, sizeof hdr);
+	if (hdr.error) {
+		ctx->err = "vgsdf_outlines_prepare: outlines flatten to more than 2^28 points per glyph / 2^32 - 1 segments per batch, or a "
+		           "bitmap exceeds 2^32 pixels (non-finite or absurd control points?)";
 		return VGSDF_E_ARG;
 	}
-
-	FE_TRY(fe.ptx.ensure(8 * (size_t)n_points + 8));
-	FE_TRY(fe.pty.ensure(8 * (size_t)n_points + 8));
-	// a ring of k points yields at most k segments: n_points bounds the segment count
-	FE_TRY(fe.sx.ensure(8 * (size_t)n_points + 8));
-	FE_TRY(fe.sy.ensure(8 * (size_t)n_points + 8));
-	FE_TRY(fe.ex.ensure(8 * (size_t)n_points + 8));
-	FE_TRY(fe.ey.ensure(8 * (size_t)n_points + 8));
-
-	FE_KERNEL(vgsdf_outline_emit(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, (const uint32_t *)fe.pt_off.p,
-	                             (double *)fe.ptx.p, (double *)fe.pty.p, fe.cmd_box.p, st));
-	FE_KERNEL(vgsdf_outline_rings(d_cmds, d_cmd_off, (const uint32_t *)fe.pt_off.p, (const double *)fe.ptx.p,
-	                              (const double *)fe.pty.p, d_scale, d_shift, n,
-	                              (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, (vgsdf::OutlineRect *)fe.rects.p,
-	                              (uint32_t *)fe.seg_count.p, fe.cmd_box.p, st));
-	FE_KERNEL(vgsdf_outline_scan(fe.scan_tmp.p, fe.scan_tmp.cap, (const uint32_t *)fe.seg_count.p, (uint32_t *)fe.seg_off.p,
-	                             n + 1, st));
-	FE_KERNEL(vgsdf_outline_segments((const uint32_t *)fe.pt_off.p, n_cmds, n_points, (const uint32_t *)fe.cmd_ring.p,
-	                                 (const vgsdf::RingRec *)fe.rings.p, (const vgsdf::OutlineRect *)fe.rects.p,
-	                                 (const uint32_t *)fe.seg_off.p, (const double *)fe.ptx.p, (const double *)fe.pty.p,
-	                                 d_scale, d_shift, (double *)fe.sx.p, (double *)fe.sy.p,
-	                                 (double *)fe.ex.p, (double *)fe.ey.p, st));
-	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects.p, sizeof(vgsdf::OutlineRect) * (size_t)n, hipMemcpyDeviceToHost, st));
-	FE_TRY(hipStreamSynchronize(st));
-	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
-	tr3 = fe_now();
-
-	// host: offsets, descriptors, tile list (same routing/order as the segment entry points)
-	static thread_local std::vector<uint32_t> seg_off, w, h;
-	static thread_local std::vector<int32_t> x0, y0;
-	static thread_local std::vector<uint64_t> out_off;
-	seg_off.assign(n + 1, 0);
-	out_off.assign(n + 1, 0);
-	w.resize(n);
-	h.resize(n);
-	x0.resize(n);
-	y0.resize(n);
-	uint64_t n_tiles = 0, n_pairs = 0;
-	for (uint32_t g = 0; g < n; g++) {
-		const vgsdf_rect &r = rects_out[g];
-		const uint64_t px = r.has_raster ? (uint64_t)r.w * r.h : 0;
-		if (px > 0xFFFFFFFFull - VGSDF_TILE_PIXELS) {
-			ctx->err = "vgsdf_outlines_prepare: glyph bitmap too large";
-			return VGSDF_E_ARG;
-		}
-		seg_off[g + 1] = seg_off[g] + (r.has_raster ? r.n_segments : 0);
-		x0[g] = r.x0;
-		y0[g] = r.y0;
-		w[g] = r.has_raster ? r.w : 0;
-		h[g] = r.has_raster ? r.h : 0;
-		out_off[g + 1] = out_off[g] + px;
-		n_tiles += (px + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
-		n_pairs += px * r.n_segments;
-	}
-	if (n_tiles > 0x7FFFFFFFull) {
+	if (hdr.n_spans > 0x7FFFFFFFu) {
 		ctx->err = "vgsdf_outlines_prepare: batch too large (tile count exceeds 2^31-1); split it";
 		return VGSDF_E_ARG;
 	}
-	fe.n_segs = seg_off[n];
-	fe.out_bytes = out_off[n];
-	vgsdf_batch view{};
-	view.n_glyphs = n;
-	view.seg_off = seg_off.data();
-	view.x0 = x0.data();
-	view.y0 = y0.data();
-	view.w = w.data();
-	view.h = h.data();
-	view.out_off = out_off.data();
+	// second launches when a capacity guess was too small (first batches of a context, unusual fonts)
+	const bool replan = hdr.n_spans > fe.tile_cap, reemit = hdr.n_segments > fe.seg_cap;
+	if (replan) {
+		FE_TRY(ensure_tiles((size_t)hdr.n_spans + hdr.n_spans / 4 + 1024));
+		FE_KERNEL(launch_plan());
+	}
+	if (reemit) {
+		FE_TRY(ensure_segs((size_t)hdr.n_segments + hdr.n_segments / 4 + 4096));
+		FE_KERNEL(launch_emit());
+	}
+	tr3 = fe_now();
+
+	uint64_t n_pairs = 0;
+	for (uint32_t g = 0; g < n; g++) {
+		const vgsdf_rect &r = rects_out[g];
+		if (r.has_raster)
+			n_pairs += (uint64_t)r.w * r.h * r.n_segments;
+	}
+	fe.n_segs = (uint32_t)hdr.n_segments;
+	fe.out_bytes = hdr.out_bytes;
 	vgsdf_dbatch &b = fe.batch;
 	b.stats.n_glyphs = n;
 	b.stats.n_segments = fe.n_segs;
 	b.stats.n_pixels = fe.out_bytes;
 	b.stats.n_pairs = n_pairs;
-	b.stats.n_tiles = n_tiles;
+	b.stats.n_tiles = hdr.n_spans;
 	b.stats.alg_bytes = 32 * (uint64_t)fe.n_segs + 32 * (uint64_t)n + fe.out_bytes;
 	b.out_bytes = (size_t)fe.out_bytes;
-	const size_t desc_bytes = align_up(sizeof(vgsdf::GlyphDesc) * (size_t)n, 256);
-	const size_t stage_bytes = desc_bytes + sizeof(uint2) * (size_t)n_tiles;
-	FE_TRY(fe.h_stage.ensure(stage_bytes + 16));
-	FE_TRY(fe.descs_tiles.ensure(stage_bytes + 16));
+	b.n_main = hdr.n_main;
+	b.span_list = span;
+	b.tile_order = 1; // the device-built list is dispatched in list order
 	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16));
-	auto *hd = (vgsdf::GlyphDesc *)fe.h_stage.p;
-	auto *ht = (uint2 *)((uint8_t *)fe.h_stage.p + desc_bytes);
-	const double tr4 = fe_now();
-	build_descs_and_tiles(&view, hd, ht, &b, ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 69));
-	const double tr5 = fe_now();
-	FE_TRY(hipMemcpyAsync(fe.descs_tiles.p, fe.h_stage.p, desc_bytes + sizeof(uint2) * (size_t)b.stats.n_tiles, hipMemcpyHostToDevice, st));
-	b.d_glyphs = (vgsdf::GlyphDesc *)fe.descs_tiles.p;
-	b.d_tiles = (uint2 *)((uint8_t *)fe.descs_tiles.p + desc_bytes);
+	b.d_glyphs = d_descs;
+	b.d_tiles = (uint2 *)fe.tiles.p;
 	b.d_sx = (double *)fe.sx.p;
 	b.d_sy = (double *)fe.sy.p;
 	b.d_ex = (double *)fe.ex.p;
 	b.d_ey = (double *)fe.ey.p;
 	b.d_out = (uint8_t *)fe.out.p;
-	b.d_boxes = nullptr;
-	if (b.span_list) {
-		FE_TRY(fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.n_segs, n) + 16));
-		b.d_boxes = fe.boxes.p;
-		FE_TRY((hipError_t)vgsdf_launch_chunk_boxes(b.d_glyphs, n, b.d_sx, b.d_sy, b.d_ex, b.d_ey, b.d_boxes, st));
-	}
+	b.d_boxes = span ? fe.boxes.p : nullptr;
 	fe.prepared = true;
 	if (out_bytes)
 		*out_bytes = fe.out_bytes;
 	if (n_segments)
 		*n_segments = fe.n_segs;
 	if (trace)
-		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, upload+count+scan+sync %.3f ms, emit..rects+sync %.3f ms, tiles+H2D %.3f ms (rect loop %.3f, list %.3f, H2D+boxes %.3f)\n",
-		             (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (tr3 - tr2) * 1e3, (fe_now() - tr3) * 1e3, (tr4 - tr3) * 1e3, (tr5 - tr4) * 1e3, (fe_now() - tr5) * 1e3);
+		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, upload + measure + plan + emit + read-back %.3f ms, second launches%s%s %.3f ms, host %.3f ms\n",
+		             (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, replan ? " (plan)" : "", reemit ? " (emit)" : "", (tr3 - tr2) * 1e3,
+		             (fe_now() - tr3) * 1e3);
 	return VGSDF_OK;
 }
 
@@ -990,8 +993,11 @@ int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, doubl
 	}
 	FrontEnd &fe = *ctx->fe;
 	(void)hipSetDevice(ctx->device);
-	if (fe.n_glyphs && seg_off)
-		FE_TRY(hipMemcpyAsync(seg_off, fe.seg_off.p, 4 * (size_t)(fe.n_glyphs + 1), hipMemcpyDeviceToHost, ctx->stream));
+	std::vector<vgsdf::GlyphDesc> hd;
+	if (fe.n_glyphs && seg_off) {
+		hd.resize(fe.n_glyphs);
+		FE_TRY(hipMemcpyAsync(hd.data(), fe.descs.p, sizeof(vgsdf::GlyphDesc) * (size_t)fe.n_glyphs, hipMemcpyDeviceToHost, ctx->stream));
+	}
 	const size_t nb = 8 * (size_t)fe.n_segs;
 	if (nb && sx && sy && ex && ey) {
 		FE_TRY(hipMemcpyAsync(sx, fe.sx.p, nb, hipMemcpyDeviceToHost, ctx->stream));
@@ -1000,6 +1006,10 @@ int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, doubl
 		FE_TRY(hipMemcpyAsync(ey, fe.ey.p, nb, hipMemcpyDeviceToHost, ctx->stream));
 	}
 	FE_TRY(hipStreamSynchronize(ctx->stream));
+	for (uint32_t g = 0; g < (uint32_t)hd.size(); g++) {
+		seg_off[g] = hd[g].seg_off;
+		seg_off[g + 1] = hd[g].seg_off + hd[g].n_seg;
+	}
 	return VGSDF_OK;
 }
 
