@@ -153,3 +153,31 @@ def test_front_end_argument_validation(vg, ctx):
     rects, out_bytes, n_segs = ctx.outlines_prepare(np.array([0, 5], np.uint32), good, sc, sh)
     assert int(rects[0]["has_raster"]) == 1 and n_segs == 3 and out_bytes == int(rects[0]["w"]) * int(rects[0]["h"])
     assert ctx.outlines_render().size == out_bytes
+
+
+def test_point_count_overflow_is_an_error_not_a_fault(vg, ctx):
+    """a curve that never becomes flat (non-finite or absurd control points) emits the capped
+    131072 points; tens of thousands of them overflow every 32-bit total.  The totals are kept in 64 bits on
+    the device, nothing is written past a capacity, and the batch is refused with VGSDF_E_ARG."""
+    def batch(n_glyphs, quads_per_glyph):
+        cmds = []
+        cmd_off = [0]
+        for _ in range(n_glyphs):
+            cmds.append((0, 0, 0, 0, 0.0, 0.0, 0))  # move_to
+            for i in range(quads_per_glyph):
+                cmds.append((1e30, -1e30, 0, 0, float(i + 1), 0.0, 2))  # quad_to with an absurd control point
+            cmds.append((0, 0, 0, 0, 0, 0, 4))  # close
+            cmd_off.append(len(cmds))
+        n = n_glyphs
+        return (np.array(cmd_off, np.uint32), np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE), np.full(n, 0.024), np.zeros(n))
+    # one glyph beyond 2^28 points (3000 x 131072)
+    with pytest.raises(vg.VgsdfError, match="2\\^28"):
+        ctx.outlines_prepare(*batch(1, 3000))
+    # every glyph below 2^28 points, the batch beyond 2^32 segments (40 x 1000 x 131072 = 5.2e9)
+    with pytest.raises(vg.VgsdfError, match="2\\^32"):
+        ctx.outlines_prepare(*batch(40, 1000))
+    # the context is still usable
+    cmd_off, cmds, scale, shift = batch(1, 1)
+    cmds["x1"], cmds["y1"] = 5.0, 5.0
+    rects, _, n_segs = ctx.outlines_prepare(cmd_off, cmds, scale, shift)
+    assert len(rects) == 1 and n_segs >= 0

@@ -32,11 +32,14 @@
 namespace vgsdf {
 
 constexpr double kTolSq = 0.01; // ring_builder.rs:62 `precision`, passed as tolerance_sq (:91,:108)
-constexpr int kMaxStack = 18;   // the work list holds depth + 1 entries; flatness shrinks 4x per level, so depth 16
-                                // covers control polygons up to ~4e8 font units.  Deeper (non-finite / absurd
-                                // input, where the reference would never finish) is cut off: a curve emits at
-                                // most 65 536 points.  (A stack-free variant that re-derives each node from
-                                // the root measured slower than the scratch stack: 160 vs 100 us per pass.)
+constexpr int kMaxStack = 18;   // the work list holds at most this many pending halves; flatness shrinks 4x per level,
+                                // so that covers control polygons up to ~4e8 font units
+constexpr uint32_t kMaxCurvePoints = 1u << 17;
+// Non-finite or absurd control points never become flat (the reference would not terminate, or would emit
+// ~2^52 points): a curve stops subdividing once its work list is full or it has emitted kMaxCurvePoints points;
+// what is still pending then emits its end point only, so a curve yields at most kMaxCurvePoints + kMaxStack
+// points and every loop below ends.  (A full work list alone does not bound the loop: the right spine of the
+// subdivision tree is reached with an empty list at any depth.)
 
 // Iterative de Casteljau, explicit LIFO stack, right half pushed first (ring.rs:119-144).
 // Calls emit(x, y) for every point appended to the ring, in order.  Returns the count.
@@ -89,7 +92,7 @@ template <class Emit> __device__ __forceinline__ uint32_t flatten_quad(double sx
 		const double dy = qsy + qey - qcy * 2.0;
 		// (non-finite control points never become flat: the reference would not terminate;
 		// here the work list is bounded and the end point is emitted)
-		if (dx * dx + dy * dy <= kTolSq || n + 2 > kMaxStack) {
+		if (dx * dx + dy * dy <= kTolSq || n + 2 > kMaxStack || count >= kMaxCurvePoints) {
 			emit(qex, qey);
 			count++;
 			if (n == 0)
@@ -125,7 +128,7 @@ __device__ __forceinline__ uint32_t flatten_cubic(double sx, double sy, double a
 		             e1 = st[n][7];
 		const double dx = (b0 + a0) - (s0 + e0);
 		const double dy = (b1 + a1) - (s1 + e1);
-		if (dx * dx + dy * dy <= kTolSq || n + 2 > kMaxStack) {
+		if (dx * dx + dy * dy <= kTolSq || n + 2 > kMaxStack || count >= kMaxCurvePoints) {
 			emit(e0, e1);
 			count++;
 			continue;
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	auto classify = [&](const OutlineRect &r, uint32_t &cls, uint32_t &T, uint32_t &nspans, uint32_t &weight) {
 		const unsigned long long px = r.has_raster ? (unsigned long long)r.w * r.h : 0ull;
 		cls = 0, T = 1, nspans = 0, weight = 0;
-		if (px == 0)
+		if (px == 0 || px > 0xFFFFFFFFull - 256ull) // (a bitmap beyond 2^32 pixels is an error of the batch: no entries)
 			return;
 		const uint32_t nseg = r.n_segments;
 		if (!fits(r.w, 1) || nseg >= (1u << 24)) {
@@ -626,7 +629,9 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	const bool any_bad = __syncthreads_or(bad);
 	if (tid == 0 && any_bad)
 		hdr->error = 1;
-	if (s_nall > tile_cap) // the host grows the list and runs the plan again
+	// no work list for a batch in error (its sizes may be absurd), nor when the list does not fit: the host
+	// grows it and runs the plan again
+	if (any_bad || error_flag[0] != 0 || s_carry[0] > 0xFFFFFFFFull || s_nall > tile_cap || s_nall > 0x7FFFFFFFu)
 		return;
 	// pass B: entries.  One per span of T tiles: (glyph, first pixel | T) in the span list's main class, else
 	// (glyph, first pixel).

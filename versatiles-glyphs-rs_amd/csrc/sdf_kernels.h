@@ -37,5 +37,8 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 // chunk boxes of a resident batch (sdf_chunk_boxes): table size, and the preparation launch.  `boxes`
 // may be NULL in vgsdf_launch_tiles (no chunk is skipped then); only the span kernel reads it.
 extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs);
+// guard (may be NULL): a vgsdf::PlanHeader on the device; the pass does nothing when it reports an error or more
+// segments than seg_cap (device front-end: the segment arrays are then empty)
 extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t n_glyphs, const double *sx, const double *sy,
-                                        const double *ex, const double *ey, void *boxes, hipStream_t stream);
+                                        const double *ex, const double *ey, void *boxes, const void *guard,
+                                        unsigned long long seg_cap, hipStream_t stream);

@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <cstdio>
 
+#include "outline_kernels.h" // PlanHeader (guard of the chunk-box pass behind the device front-end)
 #include "sdf_kernels.h"
 
 namespace vgsdf {
@@ -210,8 +211,13 @@ __global__ __launch_bounds__(256) void sdf_chunk_boxes(const GlyphDesc *__restri
                                                       const double *__restrict__ seg_sx,
                                                       const double *__restrict__ seg_sy,
                                                       const double *__restrict__ seg_ex,
-                                                      const double *__restrict__ seg_ey, float4 *__restrict__ boxes)
+                                                      const double *__restrict__ seg_ey, float4 *__restrict__ boxes,
+                                                      const PlanHeader *__restrict__ guard, unsigned long long seg_cap)
 {
+	// behind the device front-end: the segment arrays hold nothing (and are smaller than the descriptors say)
+	// when the batch is in error or did not fit its capacity guess; the host then launches again
+	if (guard != nullptr && (guard->error || guard->n_segments > seg_cap))
+		return;
 	// grid = (glyphs, CHUNK_BOX_Y): chunk c of a glyph is taken by the wave with blockIdx.y == c % gridDim.y, so
 	// the 18 chunks of a long glyph are not walked one after the other by a single wave
 	// one wave per (glyph, chunk mod gridDim.y); four glyphs per workgroup (fewer, larger workgroups to dispatch)
@@ -834,12 +840,13 @@ extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs)
 }
 
 extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t n_glyphs, const double *sx, const double *sy,
-                                        const double *ex, const double *ey, void *boxes, hipStream_t stream)
+                                        const double *ex, const double *ey, void *boxes, const void *guard,
+                                        unsigned long long seg_cap, hipStream_t stream)
 {
 	if (n_glyphs == 0)
 		return 0;
 	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3((n_glyphs + 3) / 4, 4), dim3(256), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
-	                   (float4 *)boxes);
+	                   (float4 *)boxes, (const vgsdf::PlanHeader *)guard, seg_cap);
 	return (int)hipGetLastError();
 }
 

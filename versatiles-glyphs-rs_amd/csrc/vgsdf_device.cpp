@@ -586,7 +586,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 				e = hipMemcpyAsync(b->d_ey, in->seg_ey, nb, hipMemcpyHostToDevice, ctx->stream);
 		}
 		if (e == hipSuccess && b->span_list)
-			e = (hipError_t)vgsdf_launch_chunk_boxes(b->d_glyphs, n, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_boxes, ctx->stream);
+			e = (hipError_t)vgsdf_launch_chunk_boxes(b->d_glyphs, n, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_boxes, nullptr, 0, ctx->stream);
 		// page-locked caller arrays are DMA'd in place: the copies must be over before the caller may
 		// touch them again (vgsdf.h: the batch is read-only "for the call")
 		if (e == hipSuccess && direct)
@@ -869,7 +869,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		                                    (double *)fe.ey.p, st);
 		if (e == 0 && span)
 			e = vgsdf_launch_chunk_boxes(d_descs, n, (const double *)fe.sx.p, (const double *)fe.sy.p, (const double *)fe.ex.p,
-			                             (const double *)fe.ey.p, fe.boxes.p, st);
+			                             (const double *)fe.ey.p, fe.boxes.p, d_hdr, (unsigned long long)fe.seg_cap, st);
 		return e;
 	};
 	FE_KERNEL(vgsdf_outline_context(d_cmds, d_cmd_off, d_scale, n, (uint8_t *)fe.cmd_open.p, st));
@@ -897,7 +897,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	vgsdf::PlanHeader hdr;
 	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + hdr_off, sizeof hdr);
 	if (hdr.error) {
-		ctx->err = "vgsdf_outlines_prepare: outlines flatten to more than 2^28 points per glyph / 2^32 - 1 segments per batch, or a "
+		ctx->err = "vgsdf_outlines_prepare: a glyph flattens to more than 2^28 points, the batch to more than 2^32 - 1 segments, or a "
 		           "bitmap exceeds 2^32 pixels (non-finite or absurd control points?)";
 		return VGSDF_E_ARG;
 	}
