@@ -67,6 +67,6 @@ int vgsdf_outline_plan(const vgsdf::OutlineRect *rects, uint32_t n_glyphs, int s
                        const uint32_t *error_flag, hipStream_t stream);
 int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const double *scale, const double *shift_x,
                                 const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,
-                                const vgsdf::GlyphDesc *descs, const vgsdf::PlanHeader *hdr, unsigned long long seg_cap, double *sx,
-                                double *sy, double *ex, double *ey, hipStream_t stream);
+                                const vgsdf::GlyphDesc *descs, const vgsdf::PlanHeader *hdr, unsigned long long seg_cap,
+                                double *seg /* records {sx, sy, ex, ey} */, hipStream_t stream);
 }

@@ -51,7 +51,7 @@ constexpr uint32_t kMaxCurvePoints = 1u << 17;
 // levels of every lane live in LDS ([component][level][lane]: conflict-free); a private array in
 // scratch memory took ~1 us per push/pop and made the two flattening passes the longest kernels
 // of the front-end.  Deeper levels (control polygons > ~10^4 font units) use a scratch array.
-constexpr int kLdsLevels = 8;
+constexpr int kLdsLevels = 6;
 struct QuadStack {
 	double *lds;                            // [4][kLdsLevels][64], this lane's column pre-offset
 	double deep[kMaxStack - kLdsLevels][4]; // levels kLdsLevels.. (rare)
@@ -79,8 +79,11 @@ struct QuadStack {
 	}
 };
 
-template <class Emit> __device__ __forceinline__ uint32_t flatten_quad(double sx, double sy, double cx, double cy,
-                                                                         double ex, double ey, double *lds_col, Emit emit)
+// CAPPED = false is for curves whose subdivision provably ends within 16 levels (see flatten_quad_any): no
+// bookkeeping in the loop.  CAPPED = true bounds the loop as described at kMaxCurvePoints.
+template <bool CAPPED, class Emit>
+__device__ __forceinline__ uint32_t flatten_quad(double sx, double sy, double cx, double cy, double ex, double ey,
+                                                 double *lds_col, Emit emit)
 {
 	QuadStack st;
 	st.lds = lds_col;
@@ -92,7 +95,7 @@ template <class Emit> __device__ __forceinline__ uint32_t flatten_quad(double sx
 		const double dy = qsy + qey - qcy * 2.0;
 		// (non-finite control points never become flat: the reference would not terminate;
 		// here the work list is bounded and the end point is emitted)
-		if (dx * dx + dy * dy <= kTolSq || n + 2 > kMaxStack || count >= kMaxCurvePoints) {
+		if (dx * dx + dy * dy <= kTolSq || (CAPPED && (n + 2 > kMaxStack || count >= kMaxCurvePoints))) {
 			emit(qex, qey);
 			count++;
 			if (n == 0)
@@ -110,6 +113,21 @@ template <class Emit> __device__ __forceinline__ uint32_t flatten_quad(double sx
 		qcx = m1x, qcy = m1y, qex = mx, qey = my; // left half (s, m1, m)
 	}
 	return count;
+}
+
+// A quadratic's deviation s + e - 2c is quartered by every halving (exactly, up to roundings of the size of an ulp
+// of the coordinates), so its square falls 16-fold per level: with the root's at most 0.01 * 16^14 and
+// coordinates below 1e9 (ulp 1e-7, far below the tolerance) the loop ends within 16 levels and the work list
+// never holds more than 16 entries — every curve of a real font.  Anything else takes the capped loop.
+template <class Emit>
+__device__ __forceinline__ uint32_t flatten_quad_any(double sx, double sy, double cx, double cy, double ex, double ey,
+                                                     double *lds_col, Emit emit)
+{
+	const double dx = sx + ex - cx * 2.0, dy = sy + ey - cy * 2.0;
+	const double m = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(cx), fabs(cy))), fmax(fabs(ex), fabs(ey)));
+	if (dx * dx + dy * dy <= 7.2e14 && m <= 1.0e9) // (false for NaN / inf)
+		return flatten_quad<false>(sx, sy, cx, cy, ex, ey, lds_col, emit);
+	return flatten_quad<true>(sx, sy, cx, cy, ex, ey, lds_col, emit);
 }
 
 // ring.rs:159-187
@@ -163,7 +181,7 @@ __device__ __forceinline__ uint32_t run_command(const OutlineCmd &c, bool ring_o
 	case CMD_QUAD: // :82-93
 		if (!ring_open)
 			return 0;
-		return flatten_quad(lastx, lasty, (double)c.x1, (double)c.y1, (double)c.x, (double)c.y, lds_col, emit);
+		return flatten_quad_any(lastx, lasty, (double)c.x1, (double)c.y1, (double)c.x, (double)c.y, lds_col, emit);
 	case CMD_CURVE: // :98-110
 		if (!ring_open)
 			return 0;
@@ -654,7 +672,8 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 // emit: thread per command — the second flattening pass.  Point i of a ring of n points is the start of segment i
 // (i <= n - 2, or i == n - 1 when Ring::close appended the first point again) and the end of segment i - 1; with
 // the appended point, point 0 also ends segment n - 1 (Rings::get_segments, rings.rs:75-81) — written straight
-// into the SoA arrays after scale + translate (renderer.rs:122-131).  A command that belongs to a ring has the
+// into the segment records {sx, sy, ex, ey} after scale + translate (renderer.rs:122-131); the raster reads
+// them with a stride of four doubles.  A command that belongs to a ring has the
 // ring open in front of it unless it opened the ring itself (move_to / line_to, which do not care).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const OutlineCmd *__restrict__ cmds, uint32_t n_cmds,
@@ -665,9 +684,7 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
                                                                          const uint32_t *__restrict__ cmd_ring,
                                                                          const GlyphDesc *__restrict__ descs,
                                                                          const PlanHeader *__restrict__ hdr,
-                                                                         unsigned long long seg_cap, double *__restrict__ sx,
-                                                                         double *__restrict__ sy, double *__restrict__ ex,
-                                                                         double *__restrict__ ey)
+                                                                         unsigned long long seg_cap, double2 *__restrict__ seg)
 {
 	__shared__ double s_stack[4 * kLdsLevels * 64];
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -696,17 +713,13 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 		y *= sc;
 		x += dx; // point.rs:83-86
 		y += 0.0;
-		if (idx + 1 < n || r.append) { // start of segment idx
-			sx[seg0 + idx] = x;
-			sy[seg0 + idx] = y;
-		}
-		if (idx >= 1) { // end of segment idx - 1
-			ex[seg0 + idx - 1] = x;
-			ey[seg0 + idx - 1] = y;
-		} else if (r.append) { // the closing segment returns to the first point
-			ex[seg0 + last_seg] = x;
-			ey[seg0 + last_seg] = y;
-		}
+		// records {sx, sy, ex, ey}: two 16-byte stores per point, side by side in memory
+		if (idx + 1 < n || r.append) // start of segment idx
+			seg[2 * (seg0 + idx)] = make_double2(x, y);
+		if (idx >= 1) // end of segment idx - 1
+			seg[2 * (seg0 + idx - 1) + 1] = make_double2(x, y);
+		else if (r.append) // the closing segment returns to the first point
+			seg[2 * (seg0 + last_seg) + 1] = make_double2(x, y);
 		idx++;
 	});
 }
@@ -758,12 +771,12 @@ extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, i
 
 extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cmds, const double *scale, const double *shift_x,
                                            const uint32_t *pt_local, const RingRec *rings, const uint32_t *cmd_ring,
-                                           const GlyphDesc *descs, const PlanHeader *hdr, unsigned long long seg_cap, double *sx,
-                                           double *sy, double *ex, double *ey, hipStream_t stream)
+                                           const GlyphDesc *descs, const PlanHeader *hdr, unsigned long long seg_cap, double *seg,
+                                           hipStream_t stream)
 {
 	if (n_cmds == 0)
 		return 0;
 	hipLaunchKernelGGL(outline_emit_segments, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream,
-	                   cmds, n_cmds, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, sx, sy, ex, ey);
+	                   cmds, n_cmds, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg);
 	return (int)hipGetLastError();
 }

@@ -27,12 +27,14 @@ extern "C" int vgsdf_filtered_delta_cap(void);
 // only with -DVGSDF_DEV_VARIANTS)
 extern "C" int vgsdf_kernel_known(int kernel);
 
+// Segment layout: seg_stride 1 = four SoA arrays as the C ABI hands them (vgsdf_batch); 4 = records {sx, sy, ex, ey} of
+// 32 bytes with sx / sy / ex / ey pointing at the four fields of record 0 (what the device front-end writes).
 // tiles[i] = (glyph index, first output byte of the tile inside that glyph's bitmap)
 // list_order != 0: workgroups take tiles in list order; 0: per-XCD contiguous remap
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
                                   const uint2 *tiles, uint32_t n_tiles, const double *sx,
-                                  const double *sy, const double *ex, const double *ey, uint8_t *out,
-                                  const void *boxes, hipStream_t stream);
+                                  const double *sy, const double *ex, const double *ey, uint32_t seg_stride,
+                                  uint8_t *out, const void *boxes, hipStream_t stream);
 
 // chunk boxes of a resident batch (sdf_chunk_boxes): table size, and the preparation launch.  `boxes`
 // may be NULL in vgsdf_launch_tiles (no chunk is skipped then); only the span kernel reads it.
@@ -40,5 +42,5 @@ extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs);
 // guard (may be NULL): a vgsdf::PlanHeader on the device; the pass does nothing when it reports an error or more
 // segments than seg_cap (device front-end: the segment arrays are then empty)
 extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t n_glyphs, const double *sx, const double *sy,
-                                        const double *ex, const double *ey, void *boxes, const void *guard,
-                                        unsigned long long seg_cap, hipStream_t stream);
+                                        const double *ex, const double *ey, uint32_t seg_stride, void *boxes,
+                                        const void *guard, unsigned long long seg_cap, hipStream_t stream);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
                                                        const double *__restrict__ seg_sx,
                                                        const double *__restrict__ seg_sy,
                                                        const double *__restrict__ seg_ex,
-                                                       const double *__restrict__ seg_ey,
+                                                       const double *__restrict__ seg_ey, uint32_t seg_stride,
                                                        uint8_t *__restrict__ out)
 {
 	__shared__ double s_vx[SEG_CHUNK], s_vy[SEG_CHUNK], s_wx[SEG_CHUNK], s_wy[SEG_CHUNK];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
 		const uint32_t cnt = min((uint32_t)SEG_CHUNK, g.n_seg - c0);
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
-			const uint32_t s = g.seg_off + c0 + i;
+			const size_t s = (size_t)(g.seg_off + c0 + i) * seg_stride; // stride 1: four SoA arrays; 4: {sx, sy, ex, ey} records
 			const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
 			const double dx = wx - vx, dy = wy - vy; // segment.rs:63 (w.x - v.x), (w.y - v.y)
 			s_vx[i] = vx;
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(256) void sdf_chunk_boxes(const GlyphDesc *__restri
                                                       const double *__restrict__ seg_sx,
                                                       const double *__restrict__ seg_sy,
                                                       const double *__restrict__ seg_ex,
-                                                      const double *__restrict__ seg_ey, float4 *__restrict__ boxes,
-                                                      const PlanHeader *__restrict__ guard, unsigned long long seg_cap)
+                                                      const double *__restrict__ seg_ey, uint32_t seg_stride,
+                                                      float4 *__restrict__ boxes, const PlanHeader *__restrict__ guard,
+                                                      unsigned long long seg_cap)
 {
 	// behind the device front-end: the segment arrays hold nothing (and are smaller than the descriptors say)
 	// when the batch is in error or did not fit its capacity guess; the host then launches again
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void sdf_chunk_boxes(const GlyphDesc *__restri
 		float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
 		bool bad = false;
 		for (uint32_t i = lane; i < cnt; i += 64) {
-			const uint32_t s = g.seg_off + c0 + i;
+			const size_t s = (size_t)(g.seg_off + c0 + i) * seg_stride;
 			const double rvx = seg_sx[s] - (double)g.x0, rvy = seg_sy[s] - (double)g.y0;
 			const double rwx = seg_ex[s] - (double)g.x0, rwy = seg_ey[s] - (double)g.y0;
 			const float a = (float)rvx, b = (float)rvy, cx = (float)rwx, d = (float)rwy;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
                                                       const double *__restrict__ seg_sx,
                                                       const double *__restrict__ seg_sy,
                                                       const double *__restrict__ seg_ex,
-                                                      const double *__restrict__ seg_ey,
+                                                      const double *__restrict__ seg_ey, uint32_t seg_stride,
                                                       uint8_t *__restrict__ out, const float4 *__restrict__ boxes,
                                                       unsigned long long *__restrict__ dbg)
 {
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
 			uint32_t nrow = 0; // sample rows of the span this thread's segment crosses: yy in [ya, ya + nrow)
 			int ya = 0;
 			if (i < cnt) {
-				const uint32_t s = g.seg_off + c0 + i;
+				const size_t s = (size_t)(g.seg_off + c0 + i) * seg_stride; // stride 1: SoA arrays; 4: {sx, sy, ex, ey} records
 				const double vx = seg_sx[s], vy = seg_sy[s], wx = seg_ex[s], wy = seg_ey[s];
 				e_vx[i] = vx;
 				e_vy[i] = vy;
@@ -840,13 +841,13 @@ extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs)
 }
 
 extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t n_glyphs, const double *sx, const double *sy,
-                                        const double *ex, const double *ey, void *boxes, const void *guard,
-                                        unsigned long long seg_cap, hipStream_t stream)
+                                        const double *ex, const double *ey, uint32_t seg_stride, void *boxes,
+                                        const void *guard, unsigned long long seg_cap, hipStream_t stream)
 {
 	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3((n_glyphs + 3) / 4, 4), dim3(256), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
-	                   (float4 *)boxes, (const vgsdf::PlanHeader *)guard, seg_cap);
+	hipLaunchKernelGGL(vgsdf::sdf_chunk_boxes, dim3((n_glyphs + 3) / 4, 8), dim3(256), 0, stream, glyphs, n_glyphs, sx, sy, ex, ey,
+	                   seg_stride, (float4 *)boxes, (const vgsdf::PlanHeader *)guard, seg_cap);
 	return (int)hipGetLastError();
 }
 
@@ -866,8 +867,8 @@ extern "C" int vgsdf_kernel_known(int kernel)
 
 extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::GlyphDesc *glyphs,
                                   const uint2 *tiles, uint32_t n_tiles_in, const double *sx,
-                                  const double *sy, const double *ex, const double *ey, uint8_t *out,
-                                  const void *boxes, hipStream_t stream)
+                                  const double *sy, const double *ex, const double *ey, uint32_t seg_stride,
+                                  uint8_t *out, const void *boxes, hipStream_t stream)
 {
 	if (n_tiles_in == 0)
 		return 0;
@@ -876,14 +877,16 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
 #define VG_LAUNCH_SPAN(A)                                                                                 \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
-	                   sx, sy, ex, ey, out, (const float4 *)boxes, (unsigned long long *)nullptr)
+	                   sx, sy, ex, ey, seg_stride, out, (const float4 *)boxes, (unsigned long long *)nullptr)
 	if (variant == 1)
 		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
-		                   tiles, n_tiles, sx, sy, ex, ey, out);
+		                   tiles, n_tiles, sx, sy, ex, ey, seg_stride, out);
 	else if (variant == 50) // bounded groups over spans of up to 4 tiles (tile list: first pixel | T)
 		VG_LAUNCH_SPAN(0);
 #ifdef VGSDF_DEV_VARIANTS
 	// development builds only (`make dev`): timing-only ablations (WRONG pixels) and earlier generations
+	else if (seg_stride != 1 && !(variant >= 50 && variant <= 69)) // the earlier generations read SoA arrays only
+		return (int)hipErrorInvalidValue;
 #define VG_LAUNCH_PK(A, C, P)                                                                            \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_pk<A, C, P>), grid, dim3(vgsdf::TPB / P), 0, stream, glyphs, tiles,  \
 	                   n_tiles, sx, sy, ex, ey, out)
@@ -917,7 +920,7 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 			return (int)hipErrorOutOfMemory;
 		(void)hipMemsetAsync(d_dbg, 0, 24 * sizeof(unsigned long long), stream);
 		hipLaunchKernelGGL((vgsdf::sdf_tiles_span<256>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles, sx, sy, ex,
-		                   ey, out, (const float4 *)boxes, d_dbg);
+		                   ey, seg_stride, out, (const float4 *)boxes, d_dbg);
 		unsigned long long h[24];
 		(void)hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream);
 		(void)hipStreamSynchronize(stream);

@@ -64,6 +64,7 @@ struct vgsdf_dbatch {
 	uint2 *d_tiles = nullptr;
 	void *d_boxes = nullptr; // chunk boxes (span kernel); NULL: none
 	double *d_sx = nullptr, *d_sy = nullptr, *d_ex = nullptr, *d_ey = nullptr;
+	uint32_t seg_stride = 1; // 1: four SoA arrays (C ABI batches); 4: 32-byte records (device front-end)
 	uint8_t *d_out = nullptr;
 	size_t out_bytes = 0;
 	// work list = [main kernel | brute force]
@@ -104,7 +105,7 @@ struct DevBuf {
 struct FrontEnd {
 	// device: inputs, per-command / per-ring intermediates, results of measure + plan, the resident batch
 	DevBuf cmds, meta, cmd_open, counts, pt_local, cmd_box, rings, cmd_ring, rects_hdr, descs, tiles, flag;
-	DevBuf sx, sy, ex, ey, out, boxes;
+	DevBuf seg, out, boxes; // seg: records {sx, sy, ex, ey}
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
 	uint32_t n_glyphs = 0, n_cmds = 0, n_segs = 0;
@@ -119,8 +120,8 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &sx, &sy, &ex, &ey,
-		                  &out, &boxes, &h_rects, &h_stage})
+		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes,
+		                  &h_rects, &h_stage})
 			b->release();
 	}
 };
@@ -586,7 +587,7 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 				e = hipMemcpyAsync(b->d_ey, in->seg_ey, nb, hipMemcpyHostToDevice, ctx->stream);
 		}
 		if (e == hipSuccess && b->span_list)
-			e = (hipError_t)vgsdf_launch_chunk_boxes(b->d_glyphs, n, b->d_sx, b->d_sy, b->d_ex, b->d_ey, b->d_boxes, nullptr, 0, ctx->stream);
+			e = (hipError_t)vgsdf_launch_chunk_boxes(b->d_glyphs, n, b->d_sx, b->d_sy, b->d_ex, b->d_ey, 1, b->d_boxes, nullptr, 0, ctx->stream);
 		// page-locked caller arrays are DMA'd in place: the copies must be over before the caller may
 		// touch them again (vgsdf.h: the batch is read-only "for the call")
 		if (e == hipSuccess && direct)
@@ -645,10 +646,10 @@ int vgsdf_batch_launch(vgsdf_ctx *ctx, vgsdf_dbatch *b)
 	}
 	const int list_order = b->tile_order == 1;
 	int e = vgsdf_launch_tiles(k_main, list_order, b->d_glyphs, b->d_tiles, n_main, b->d_sx, b->d_sy, b->d_ex, b->d_ey,
-	                           b->d_out, b->span_list ? b->d_boxes : nullptr, ctx->stream);
+	                           b->seg_stride, b->d_out, b->span_list ? b->d_boxes : nullptr, ctx->stream);
 	if (e == 0)
 		e = vgsdf_launch_tiles(1, list_order, b->d_glyphs, b->d_tiles + n_main, n_all - n_main, b->d_sx, b->d_sy, b->d_ex,
-		                       b->d_ey, b->d_out, nullptr, ctx->stream);
+		                       b->d_ey, b->seg_stride, b->d_out, nullptr, ctx->stream);
 	if (e != 0) {
 		ctx->err = std::string("vgsdf_batch_launch: ") + hipGetErrorString((hipError_t)e);
 		return VGSDF_E_HIP;
@@ -824,10 +825,9 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	auto ensure_segs = [&](size_t want) -> hipError_t {
 		if (want <= fe.seg_cap)
 			return hipSuccess;
-		for (DevBuf *b : {&fe.sx, &fe.sy, &fe.ex, &fe.ey})
-			if (hipError_t e = b->ensure(8 * want + 8); e != hipSuccess)
-				return e;
-		fe.seg_cap = std::min({fe.sx.cap, fe.sy.cap, fe.ex.cap, fe.ey.cap}) / 8 - 1;
+		if (hipError_t e = fe.seg.ensure(32 * want + 32); e != hipSuccess)
+			return e;
+		fe.seg_cap = fe.seg.cap / 32 - 1;
 		return fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.seg_cap, n) + 16);
 	};
 	FE_TRY(ensure_tiles(2 * (size_t)n + 1024));
@@ -865,11 +865,10 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	auto launch_emit = [&]() -> int {
 		int e = vgsdf_outline_emit_segments(d_cmds, n_cmds, d_scale, d_shift, (const uint32_t *)fe.pt_local.p,
 		                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d_descs, d_hdr,
-		                                    (unsigned long long)fe.seg_cap, (double *)fe.sx.p, (double *)fe.sy.p, (double *)fe.ex.p,
-		                                    (double *)fe.ey.p, st);
+		                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, st);
 		if (e == 0 && span)
-			e = vgsdf_launch_chunk_boxes(d_descs, n, (const double *)fe.sx.p, (const double *)fe.sy.p, (const double *)fe.ex.p,
-			                             (const double *)fe.ey.p, fe.boxes.p, d_hdr, (unsigned long long)fe.seg_cap, st);
+			e = vgsdf_launch_chunk_boxes(d_descs, n, (const double *)fe.seg.p, (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2,
+			                             (const double *)fe.seg.p + 3, 4, fe.boxes.p, d_hdr, (unsigned long long)fe.seg_cap, st);
 		return e;
 	};
 	FE_KERNEL(vgsdf_outline_context(d_cmds, d_cmd_off, d_scale, n, (uint8_t *)fe.cmd_open.p, st));
@@ -939,10 +938,11 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16));
 	b.d_glyphs = d_descs;
 	b.d_tiles = (uint2 *)fe.tiles.p;
-	b.d_sx = (double *)fe.sx.p;
-	b.d_sy = (double *)fe.sy.p;
-	b.d_ex = (double *)fe.ex.p;
-	b.d_ey = (double *)fe.ey.p;
+	b.d_sx = (double *)fe.seg.p;
+	b.d_sy = (double *)fe.seg.p + 1;
+	b.d_ex = (double *)fe.seg.p + 2;
+	b.d_ey = (double *)fe.seg.p + 3;
+	b.seg_stride = 4;
 	b.d_out = (uint8_t *)fe.out.p;
 	b.d_boxes = span ? fe.boxes.p : nullptr;
 	fe.prepared = true;
@@ -998,17 +998,21 @@ int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, doubl
 		hd.resize(fe.n_glyphs);
 		FE_TRY(hipMemcpyAsync(hd.data(), fe.descs.p, sizeof(vgsdf::GlyphDesc) * (size_t)fe.n_glyphs, hipMemcpyDeviceToHost, ctx->stream));
 	}
-	const size_t nb = 8 * (size_t)fe.n_segs;
-	if (nb && sx && sy && ex && ey) {
-		FE_TRY(hipMemcpyAsync(sx, fe.sx.p, nb, hipMemcpyDeviceToHost, ctx->stream));
-		FE_TRY(hipMemcpyAsync(sy, fe.sy.p, nb, hipMemcpyDeviceToHost, ctx->stream));
-		FE_TRY(hipMemcpyAsync(ex, fe.ex.p, nb, hipMemcpyDeviceToHost, ctx->stream));
-		FE_TRY(hipMemcpyAsync(ey, fe.ey.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+	std::vector<double> rec;
+	if (fe.n_segs && sx && sy && ex && ey) {
+		rec.resize(4 * (size_t)fe.n_segs);
+		FE_TRY(hipMemcpyAsync(rec.data(), fe.seg.p, 32 * (size_t)fe.n_segs, hipMemcpyDeviceToHost, ctx->stream));
 	}
 	FE_TRY(hipStreamSynchronize(ctx->stream));
 	for (uint32_t g = 0; g < (uint32_t)hd.size(); g++) {
 		seg_off[g] = hd[g].seg_off;
 		seg_off[g + 1] = hd[g].seg_off + hd[g].n_seg;
+	}
+	for (size_t i = 0; i * 4 < rec.size(); i++) { // records -> the four arrays of the C ABI
+		sx[i] = rec[4 * i];
+		sy[i] = rec[4 * i + 1];
+		ex[i] = rec[4 * i + 2];
+		ey[i] = rec[4 * i + 3];
 	}
 	return VGSDF_OK;
 }
