@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 50 --warmup 5 --min-ms 5 --no-cpu-baseline --no-e2e --no-configs $*"
+BENCH="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-e2e --no-configs $*"  # >= 50 ms of launches: the average is not a cold one
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 # PMC passes: counters only (never combined with other trace domains on this pool)
 PMC="python3 bench.py --steps 3 --warmup 1 --min-ms 0 --no-cpu-baseline --no-e2e --no-configs $*"
