@@ -293,11 +293,17 @@ def main():
             "cycles_per_inst": pmc.get("valu_cycles_per_inst") if pmc else None,
             "pmc_kernel_ms": pmc.get("kernel_ms") if pmc else None,
             "brute_pairs_per_s": st["n_pairs"] / kernel_s,
-            "note": "from the rocprofv3 PMC passes recorded in profiles/traffic.json, reported only when that file was "
-                    "collected on the kernel sources of this build (else null): VALU instructions per wave, share of SIMD "
-                    "cycles with the VALU busy (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles)), busy cycles "
-                    "per instruction; brute_pairs_per_s = pixels x segments of the batch / kernel time, the rate a "
-                    "brute-force evaluation would need",
+            "model_cycles_per_inst": pmc.get("valu_model_cycles_per_inst") if pmc else None,
+            "mix": pmc.get("valu_mix") if pmc else None,
+            "note": "VALU issue roofline from the rocprofv3 PMC passes recorded in profiles/traffic.json, reported only "
+                    "when that file was collected on the kernel sources of this build (else null): VALU instructions per "
+                    "wave; busy_frac = sum over the kernel's dynamic instruction mix (SQ_INSTS_VALU_* classes) of the "
+                    "issue cost measured per class (tools/ubench: f32 add/mul/fma 2.5 cycles, f32 transcendental 8.5, f64 "
+                    "4.9, f64 transcendental 16.3, integer/min/max/compare/convert 4.4) / (1024 SIMDs x kernel cycles at "
+                    "2.4 GHz) = the share of the launch in which the VALU issue ports are necessarily busy; "
+                    "cycles_per_inst = SIMD cycles of the launch per VALU instruction, model_cycles_per_inst = the "
+                    "same at a fully busy port; brute_pairs_per_s = pixels x segments of the batch / kernel time, the "
+                    "rate a brute-force evaluation would need",
         },
         "host_stage_s": host_s,
     }

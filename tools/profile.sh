@@ -15,4 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC > $OUT/fetc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $PMC > $OUT/sq.log 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq2 -- $PMC > $OUT/sq2.log 2>&1 || true
+# VALU instruction classes (issue-cost model of the VALU roofline)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq3 -- $PMC > $OUT/sq3.log 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --output-format csv -d $OUT/sq4 -- $PMC > $OUT/sq4.log 2>&1 || true
 find $OUT -name "*.csv" | tail -40

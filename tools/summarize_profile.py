@@ -47,7 +47,7 @@ def pmc(sub):
 
 lines += ["", "## PMC (per launch, mean over dispatches; separate passes)", ""]
 allc = {}
-for sub in ("fetch", "write", "sq", "sq2"):
+for sub in ("fetch", "write", "sq", "sq2", "sq3", "sq4"):
     allc.update(pmc(sub))
 for k, v in sorted(allc.items()):
     lines.append(f"* {k} = {v:.6g}")
@@ -78,12 +78,32 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
         ent["valu_ginst_per_s_per_simd"] = allc["SQ_INSTS_VALU"] / 1024.0 / avg_ns
         ent["valu_issue_frac"] = ent["valu_ginst_per_s_per_simd"] / 0.96
         ent["kernel_ms"] = avg_ns * 1e-6
-        if "SQ_ACTIVE_INST_VALU" in allc:
-            # SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); 1024 SIMDs; kernel cycles at 2.4 GHz
-            ent["valu_busy_frac"] = allc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avg_ns * 2.4)
-            ent["valu_cycles_per_inst"] = allc["SQ_ACTIVE_INST_VALU"] * 4.0 / allc["SQ_INSTS_VALU"]
-            lines += ["", f"VALU busy: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x {avg_ns:.0f} ns x 2.4 GHz) = "
-                      f"**{ent['valu_busy_frac']:.2f}**; {ent['valu_cycles_per_inst']:.2f} busy cycles per VALU instruction"]
+        # Issue-cost model: every VALU instruction occupies its SIMD's issue port for a measured number of cycles
+        # (tools/ubench/valu_rate*.hip, profiles/r2_ubench.txt, at 2.4 GHz): f32 add/mul/fma 2.5, f32
+        # transcendental 8.5, f64 add/mul/fma 4.6-5.2 (4.9), f64 transcendental 16.3, everything else (integer,
+        # min/max, compare, select, convert, shifts, DPP moves) 4.2-5.3 (4.4).  The sum over the kernel's dynamic mix
+        # is the time the VALU ports are NECESSARILY busy; divided by 1024 SIMDs x kernel cycles it is the
+        # fraction of the VALU issue roofline the launch reaches.  (SQ_ACTIVE_INST_VALU is no busy-time counter on
+        # this part: it reads one unit per instruction whatever the instruction, checked with pure v_pk_fma_f32 and
+        # v_med3_u32 streams.)
+        cls = {k: allc.get("SQ_INSTS_VALU_" + k) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "ADD_F64", "MUL_F64",
+                                                            "FMA_F64", "TRANS_F64", "INT32", "INT64", "CVT")}
+        if all(v is not None for v in cls.values()):
+            f32 = cls["ADD_F32"] + cls["MUL_F32"] + cls["FMA_F32"]
+            f64 = cls["ADD_F64"] + cls["MUL_F64"] + cls["FMA_F64"]
+            other = allc["SQ_INSTS_VALU"] - f32 - f64 - cls["TRANS_F32"] - cls["TRANS_F64"]
+            cost = 2.5 * f32 + 8.5 * cls["TRANS_F32"] + 4.9 * f64 + 16.3 * cls["TRANS_F64"] + 4.4 * other
+            ent["valu_mix"] = {"f32_add_mul_fma": f32, "f32_trans": cls["TRANS_F32"], "f64_add_mul_fma": f64,
+                               "f64_trans": cls["TRANS_F64"], "int32": cls["INT32"], "int64": cls["INT64"], "cvt": cls["CVT"],
+                               "other_incl_int_cvt": other, "total": allc["SQ_INSTS_VALU"]}
+            ent["valu_issue_cycles_per_simd"] = cost / 1024.0
+            ent["valu_model_cycles_per_inst"] = cost / allc["SQ_INSTS_VALU"]
+            ent["valu_busy_frac"] = cost / (1024.0 * avg_ns * 2.4)
+            ent["valu_cycles_per_inst"] = 1024.0 * avg_ns * 2.4 / allc["SQ_INSTS_VALU"]
+            lines += ["", "VALU instruction mix per launch: " + ", ".join(f"{k} {v:.4g}" for k, v in ent["valu_mix"].items()),
+                      "", f"VALU issue roofline: sum of measured issue costs {cost / 1024.0:.4g} cycles per SIMD "
+                      f"({ent['valu_model_cycles_per_inst']:.2f} per instruction) / ({avg_ns:.0f} ns x 2.4 GHz) = "
+                      f"**{ent['valu_busy_frac']:.2f}**; the launch spends {ent['valu_cycles_per_inst']:.2f} SIMD cycles per VALU instruction"]
         lines += ["", f"VALU issue: {allc['SQ_INSTS_VALU']:.4g} instructions / 1024 SIMDs / {avg_ns:.0f} ns = "
                   f"**{ent['valu_ginst_per_s_per_simd']:.3f} G inst/s/SIMD** = {ent['valu_issue_frac']:.2f} of the measured "
                   f"full-rate f32 issue (0.96); {ent['valu_insts_per_wave']:.0f} VALU instructions per wave"]
