@@ -122,6 +122,57 @@ def test_arbitrary_command_streams(oracle, vg, ctx):
             assert rects[g]["has_raster"] == 0 and len(got) == 0, g
 
 
+def test_quadratics_at_the_flatness_threshold(oracle, vg, ctx):
+    """The flattening kernels treat a quad_to as a complete tree of depth L when |s + e - 2c|^2 / 16^L is clear of
+    tolerance^2 by 1e-6 (relative) and walk it sequentially otherwise: glyphs whose curves sit at, just inside and
+    just outside that margin at every depth, large coordinates (beyond the 1e6 bound of the argument), a scale
+    that is not monotone (boxes on transformed points), all against the oracle's sequential RingBuilder."""
+    M, L, Q, Z = 0, 1, 2, 4
+    rng = np.random.default_rng(11)
+    streams, scales = [], []
+    for lev in range(0, 9):
+        h0 = 0.05 * 4.0 ** lev  # s + e - 2c = (0, -2h): D / 16^lev = 0.01 at h = h0
+        for rel in (0.0, 3e-8, -3e-8, 4e-7, -4e-7, 9e-7, -9e-7, 1.2e-6, -1.2e-6, 3e-6, -3e-6, 1e-4, -1e-4, 0.3, -0.3):
+            h = np.float32(h0 * (1.0 + rel) ** 0.5)
+            a = np.float32(rng.uniform(50, 900))
+            ox, oy = (np.float32(v) for v in rng.uniform(-300, 300, 2))
+            st = [(M, 0, 0, 0, 0, ox, oy), (Q, ox + a, oy + h, 0, 0, ox + 2 * a, oy), (L, 0, 0, 0, 0, ox + a, oy - 500), (Z,) + (0,) * 6]
+            streams.append(st)
+            scales.append(24.0 / 1000.0)
+    # coordinates beyond the bound of the complete-tree argument; a mirrored glyph (scale < 0)
+    streams.append([(M, 0, 0, 0, 0, 2.0e6, 2.0e6), (Q, 2.0e6 + 400, 2.0e6 + 300, 0, 0, 2.0e6 + 800, 2.0e6), (L, 0, 0, 0, 0, 2.0e6 + 400, 2.0e6 - 400), (Z,) + (0,) * 6])
+    scales.append(24.0 / 1000.0)
+    streams.append([(M, 0, 0, 0, 0, 10, 10), (Q, 300, 700, 0, 0, 600, 10), (Q, 300, -200, 0, 0, 10, 10), (Z,) + (0,) * 6])
+    scales.append(-24.0 / 1000.0)
+    cmds, cmd_off = [], [0]
+    for st in streams:
+        for c in st:
+            cmds.append((c[1], c[2], c[3], c[4], c[5], c[6], c[0]))
+        cmd_off.append(len(cmds))
+    scale = np.array(scales)
+    shift = rng.uniform(-0.5, 0.5, len(streams))
+    rects, _, _ = ctx.outlines_prepare(np.array(cmd_off, np.uint32), np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE), scale, shift)
+    seg_off, segs = ctx.outlines_segments()
+    depths = set()
+    for g, st in enumerate(streams):
+        rings = oracle.build_rings([tuple(c) for c in st])
+        want = []
+        for r in rings:
+            p = r * scale[g]
+            p[:, 0] += shift[g]
+            p[:, 1] += 0.0
+            want.append(np.concatenate([p[:-1], p[1:]], axis=1))
+        want = np.concatenate(want)
+        got = segs[seg_off[g]:seg_off[g + 1]]
+        assert got.tobytes() == want.tobytes(), g
+        allp = np.concatenate([want[:, :2], want[:, 2:]])
+        assert int(rects[g]["x0"]) == int(np.floor(allp[:, 0].min())) - 3, g
+        assert int(rects[g]["y0"]) == int(np.floor(allp[:, 1].min())) - 3, g
+        assert int(rects[g]["w"]) == int(np.ceil(allp[:, 0].max())) + 3 - int(rects[g]["x0"]), g
+        depths.add(len(want))
+    assert len(depths) >= 9   # the sweep really crossed depths (3 + 2^L segments per glyph)
+
+
 @pytest.mark.parametrize("name", ["fira", "noto_all"])
 def test_pbf_sha_with_device_front_end(vg, name):
     disp, paths = set_paths(name)

@@ -65,7 +65,8 @@ int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, 
 int vgsdf_outline_plan(const vgsdf::OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
                        uint32_t span_budget, uint32_t tile_cap, vgsdf::GlyphDesc *descs, uint2 *tiles, vgsdf::PlanHeader *hdr,
                        const uint32_t *error_flag, hipStream_t stream);
-int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const double *scale, const double *shift_x,
+int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const uint8_t *cmd_open, const double *scale,
+                                const double *shift_x,
                                 const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,
                                 const vgsdf::GlyphDesc *descs, const vgsdf::PlanHeader *hdr, unsigned long long seg_cap,
                                 double *seg /* records {sx, sy, ex, ey} */, hipStream_t stream);

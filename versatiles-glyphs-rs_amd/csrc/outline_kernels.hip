@@ -13,16 +13,18 @@
 //
 // Pipeline: five launches, no intermediate point arrays, one read-back (the rects) for the host:
 //   context  wave per glyph: is the ring non-empty in front of every command
-//   count    thread per command: first flattening pass — how many points the command appends, their
+//   count    wave per 64 commands: first flattening pass — how many points every command appends, their
 //            bounding box (nothing else is stored)
 //   rings    wave per glyph: point offsets inside the glyph, ring acceptance / closing rules, segment count,
 //            bbox -> rect
 //   plan     one workgroup: segment / output offsets of all glyphs (descriptors), the raster's work list
 //            (spans, heaviest first), totals
-//   emit     thread per command: second flattening pass; every point goes straight into the scaled + shifted
-//            SoA segment arrays as the start of one segment and the end of its predecessor
-// The two flattening passes run one command per thread over the whole batch (balanced whatever the glyph
-// sizes are); a wave-per-glyph form of them measured 2.5x slower (idle lanes, 16 KB of LDS stack per wave).
+//   emit     wave per 64 commands: second flattening pass; every point goes straight into the scaled + shifted
+//            segment records as the start of one segment and the end of its predecessor
+// The two flattening passes deal the points of 64 consecutive commands out to the 64 lanes of a wave in items
+// of up to 8 points ("Leaf-parallel flattening" below); one command per thread left 63 lanes waiting for the
+// lane with a 32-point curve (36 + 45 us per Noto Sans Regular font; now 7 + 21), and a wave-per-glyph form
+// measured 2.5x slower still.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -47,46 +49,32 @@ constexpr uint32_t kMaxCurvePoints = 1u << 17;
 // The reference pushes (m, m2, e) then (s, m1, m) and pops the left half at once; what stays on its
 // stack are the right halves of the ancestors.  A right half's start point is the end point of
 // its left sibling's subtree, i.e. the point emitted last (the same f64 value m, carried down
-// unchanged), so a pending entry needs only (control, end): 4 doubles.  The first kLdsLevels
-// levels of every lane live in LDS ([component][level][lane]: conflict-free); a private array in
-// scratch memory took ~1 us per push/pop and made the two flattening passes the longest kernels
-// of the front-end.  Deeper levels (control polygons > ~10^4 font units) use a scratch array.
-constexpr int kLdsLevels = 6;
+// unchanged), so a pending entry needs only (control, end): 4 doubles.
+// These sequential walks are the EXCEPTION (see "Leaf-parallel flattening" below): one lane of a wave at a
+// time runs them, on a work list in LDS (kMaxStack entries of 8 doubles per wave).  A private array would live
+// in scratch memory: 1.2 KB per lane made the runtime set scratch up per dispatch and cost both flattening
+// kernels ~25 us each, whatever they computed.
 struct QuadStack {
-	double *lds;                            // [4][kLdsLevels][64], this lane's column pre-offset
-	double deep[kMaxStack - kLdsLevels][4]; // levels kLdsLevels.. (rare)
+	double *stk; // [kMaxStack][4]
 	__device__ __forceinline__ void push(int n, double cx, double cy, double ex, double ey)
 	{
-		if (n < kLdsLevels) {
-			lds[(0 * kLdsLevels + n) * 64] = cx;
-			lds[(1 * kLdsLevels + n) * 64] = cy;
-			lds[(2 * kLdsLevels + n) * 64] = ex;
-			lds[(3 * kLdsLevels + n) * 64] = ey;
-		} else {
-			deep[n - kLdsLevels][0] = cx, deep[n - kLdsLevels][1] = cy, deep[n - kLdsLevels][2] = ex, deep[n - kLdsLevels][3] = ey;
-		}
+		stk[4 * n + 0] = cx, stk[4 * n + 1] = cy, stk[4 * n + 2] = ex, stk[4 * n + 3] = ey;
 	}
 	__device__ __forceinline__ void pop(int n, double &cx, double &cy, double &ex, double &ey)
 	{
-		if (n < kLdsLevels) {
-			cx = lds[(0 * kLdsLevels + n) * 64];
-			cy = lds[(1 * kLdsLevels + n) * 64];
-			ex = lds[(2 * kLdsLevels + n) * 64];
-			ey = lds[(3 * kLdsLevels + n) * 64];
-		} else {
-			cx = deep[n - kLdsLevels][0], cy = deep[n - kLdsLevels][1], ex = deep[n - kLdsLevels][2], ey = deep[n - kLdsLevels][3];
-		}
+		cx = stk[4 * n + 0], cy = stk[4 * n + 1], ex = stk[4 * n + 2], ey = stk[4 * n + 3];
 	}
 };
+constexpr int kSerialStackDoubles = kMaxStack * 8;
 
 // CAPPED = false is for curves whose subdivision provably ends within 16 levels (see flatten_quad_any): no
 // bookkeeping in the loop.  CAPPED = true bounds the loop as described at kMaxCurvePoints.
 template <bool CAPPED, class Emit>
 __device__ __forceinline__ uint32_t flatten_quad(double sx, double sy, double cx, double cy, double ex, double ey,
-                                                 double *lds_col, Emit emit)
+                                                 double *stk, Emit emit)
 {
 	QuadStack st;
-	st.lds = lds_col;
+	st.stk = stk;
 	int n = 0; // pending right halves = the reference's stack size after its pop
 	uint32_t count = 0;
 	double qsx = sx, qsy = sy, qcx = cx, qcy = cy, qex = ex, qey = ey;
@@ -121,29 +109,32 @@ __device__ __forceinline__ uint32_t flatten_quad(double sx, double sy, double cx
 // never holds more than 16 entries — every curve of a real font.  Anything else takes the capped loop.
 template <class Emit>
 __device__ __forceinline__ uint32_t flatten_quad_any(double sx, double sy, double cx, double cy, double ex, double ey,
-                                                     double *lds_col, Emit emit)
+                                                     double *stk, Emit emit)
 {
 	const double dx = sx + ex - cx * 2.0, dy = sy + ey - cy * 2.0;
 	const double m = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(cx), fabs(cy))), fmax(fabs(ex), fabs(ey)));
 	if (dx * dx + dy * dy <= 7.2e14 && m <= 1.0e9) // (false for NaN / inf)
-		return flatten_quad<false>(sx, sy, cx, cy, ex, ey, lds_col, emit);
-	return flatten_quad<true>(sx, sy, cx, cy, ex, ey, lds_col, emit);
+		return flatten_quad<false>(sx, sy, cx, cy, ex, ey, stk, emit);
+	return flatten_quad<true>(sx, sy, cx, cy, ex, ey, stk, emit);
 }
 
 // ring.rs:159-187
 template <class Emit>
 __device__ __forceinline__ uint32_t flatten_cubic(double sx, double sy, double ax, double ay, double bx, double by,
-                                                  double ex, double ey, Emit emit)
+                                                  double ex, double ey, double *stk /*[kMaxStack][8], LDS*/, Emit emit)
 {
-	double st[kMaxStack][8];
 	int n = 0;
 	uint32_t count = 0;
-	st[n][0] = sx, st[n][1] = sy, st[n][2] = ax, st[n][3] = ay, st[n][4] = bx, st[n][5] = by, st[n][6] = ex, st[n][7] = ey;
+	auto put = [&](int at, double v0, double v1, double v2, double v3, double v4, double v5, double v6, double v7) {
+		double *e = stk + 8 * at;
+		e[0] = v0, e[1] = v1, e[2] = v2, e[3] = v3, e[4] = v4, e[5] = v5, e[6] = v6, e[7] = v7;
+	};
+	put(n, sx, sy, ax, ay, bx, by, ex, ey);
 	n++;
 	while (n > 0) {
 		n--;
-		const double s0 = st[n][0], s1 = st[n][1], a0 = st[n][2], a1 = st[n][3], b0 = st[n][4], b1 = st[n][5], e0 = st[n][6],
-		             e1 = st[n][7];
+		const double *t = stk + 8 * n;
+		const double s0 = t[0], s1 = t[1], a0 = t[2], a1 = t[3], b0 = t[4], b1 = t[5], e0 = t[6], e1 = t[7];
 		const double dx = (b0 + a0) - (s0 + e0);
 		const double dy = (b1 + a1) - (s1 + e1);
 		if (dx * dx + dy * dy <= kTolSq || n + 2 > kMaxStack || count >= kMaxCurvePoints) {
@@ -157,11 +148,9 @@ __device__ __forceinline__ uint32_t flatten_cubic(double sx, double sy, double a
 		const double p012x = (p01x + p12x) / 2.0, p012y = (p01y + p12y) / 2.0;
 		const double p123x = (p12x + p23x) / 2.0, p123y = (p12y + p23y) / 2.0;
 		const double mx = (p012x + p123x) / 2.0, my = (p012y + p123y) / 2.0;
-		st[n][0] = mx, st[n][1] = my, st[n][2] = p123x, st[n][3] = p123y, st[n][4] = p23x, st[n][5] = p23y, st[n][6] = e0,
-		st[n][7] = e1;
+		put(n, mx, my, p123x, p123y, p23x, p23y, e0, e1);
 		n++;
-		st[n][0] = s0, st[n][1] = s1, st[n][2] = p01x, st[n][3] = p01y, st[n][4] = p012x, st[n][5] = p012y, st[n][6] = mx,
-		st[n][7] = my;
+		put(n, s0, s1, p01x, p01y, p012x, p012y, mx, my);
 		n++;
 	}
 	return count;
@@ -170,7 +159,7 @@ __device__ __forceinline__ uint32_t flatten_cubic(double sx, double sy, double a
 // One command.  `ring_open` is false right after a CLOSE / at the glyph start, where the
 // ring is empty and quad_to / curve_to are ignored (ring_builder.rs:83-85,99-101).
 template <class Emit>
-__device__ __forceinline__ uint32_t run_command(const OutlineCmd &c, bool ring_open, double lastx, double lasty, double *lds_col,
+__device__ __forceinline__ uint32_t run_command(const OutlineCmd &c, bool ring_open, double lastx, double lasty, double *stk,
                                                 Emit emit)
 {
 	switch (c.kind) {
@@ -181,11 +170,11 @@ __device__ __forceinline__ uint32_t run_command(const OutlineCmd &c, bool ring_o
 	case CMD_QUAD: // :82-93
 		if (!ring_open)
 			return 0;
-		return flatten_quad_any(lastx, lasty, (double)c.x1, (double)c.y1, (double)c.x, (double)c.y, lds_col, emit);
+		return flatten_quad_any(lastx, lasty, (double)c.x1, (double)c.y1, (double)c.x, (double)c.y, stk, emit);
 	case CMD_CURVE: // :98-110
 		if (!ring_open)
 			return 0;
-		return flatten_cubic(lastx, lasty, (double)c.x1, (double)c.y1, (double)c.x2, (double)c.y2, (double)c.x, (double)c.y, emit);
+		return flatten_cubic(lastx, lasty, (double)c.x1, (double)c.y1, (double)c.x2, (double)c.y2, (double)c.x, (double)c.y, stk, emit);
 	default: // CMD_CLOSE
 		return 0;
 	}
@@ -240,6 +229,139 @@ __device__ __forceinline__ int32_t to_i32(double v)
 
 
 // ---------------------------------------------------------------------------------------
+// Leaf-parallel flattening of the 64 commands of a wave.
+//
+// The deviation s + e - 2c of a quadratic is quartered by every halving, exactly in real arithmetic: both halves
+// of (s, c, e) have deviation (s + e - 2c) / 4.  So the reference's adaptive subdivision (ring.rs:119-144) is a
+// COMPLETE binary tree of depth L = the first level with D / 16^L <= tolerance^2 (D = |s + e - 2c|^2 at the root),
+// unless a rounding error pushes some node across the threshold.  The computed deviation of a node at level
+// l <= 16 differs from d / 4^l by < (8 l + 8) 2^-52 M < 3e-14 M (every midpoint (a + b) / 2 rounds once, all
+// points are convex combinations of the control points, |coordinate| <= M), so for M <= 1e6 the squared
+// deviation near the threshold (|d| ~ 0.1) is off by < 6e-9 < 1e-6 * tolerance^2: when D / 16^L lies outside
+// (1 +- 1e-6) tolerance^2 at levels L - 1 and L, the tree IS complete, the command appends exactly 2^L points
+// and point r is the end point of the leaf reached from the root by the bits of r (most significant first) —
+// the same midpoint operations on the same f64 values as the sequential walk, in any order.  (All 323 k
+// quadratics of the 21 fixture fonts qualify; L is 4 or 5 for most.)  Everything else — a quadratic inside the
+// margin or with absurd coordinates, every cubic, commands of a glyph whose transform is not monotone — keeps
+// the sequential walk in its own lane.
+//
+// A wave therefore deals the points of its 64 commands out to its 64 lanes in ITEMS of up to 8 consecutive
+// points (a subtree of depth <= 3; a line is an item of one point), 64 items per round: a curve of 32 points is
+// four items and no longer keeps 63 lanes waiting, and the walk down to a subtree's root is shared by its 8 leaves.
+// ---------------------------------------------------------------------------------------
+struct WaveQuads {
+	double sx[64], sy[64], cx[64], cy[64], ex[64], ey[64];
+	uint32_t pre[65]; // exclusive sums of the commands' parallel point counts
+	uint32_t lev[64];
+};
+
+// points this command hands to the parallel rounds (0: none or sequential), its tree depth
+__device__ __forceinline__ uint32_t quad_parallel_points(double sx, double sy, double cx, double cy, double ex, double ey, uint32_t &lev)
+{
+	const double dx = sx + ex - cx * 2.0, dy = sy + ey - cy * 2.0; // ring.rs:129
+	const double D = dx * dx + dy * dy;
+	const double m = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(cx), fabs(cy))), fmax(fabs(ex), fabs(ey)));
+	lev = 0;
+	if (!(D <= 7.2e14 && m <= 1.0e6)) // (false for NaN / inf)
+		return 0;
+	double v = D;
+	uint32_t L = 0;
+	while (v > kTolSq) { // <= 14 trips
+		v *= 0.0625;
+		L++;
+	}
+	const bool certain = v <= kTolSq * (1.0 - 1.0e-6) && (L == 0 || v * 16.0 > kTolSq * (1.0 + 1.0e-6));
+	if (!certain)
+		return 0;
+	lev = L;
+	return 1u << L;
+}
+
+// the complete subtree of depth D under (s, c, e), leaves in order: emit(end point of every leaf)
+template <int D, class Emit>
+__device__ __forceinline__ void quad_subtree(double sx, double sy, double cx, double cy, double ex, double ey, Emit &emit)
+{
+	if constexpr (D == 0) {
+		emit(ex, ey);
+	} else {
+		const double m1x = (sx + cx) / 2.0, m1y = (sy + cy) / 2.0; // point.rs:29-31
+		const double m2x = (cx + ex) / 2.0, m2y = (cy + ey) / 2.0;
+		const double mx = (m1x + m2x) / 2.0, my = (m1y + m2y) / 2.0;
+		quad_subtree<D - 1>(sx, sy, m1x, m1y, mx, my, emit); // left half (s, m1, m)
+		quad_subtree<D - 1>(mx, my, m2x, m2y, ex, ey, emit); // right half (m, m2, e)
+	}
+}
+
+constexpr uint32_t kItemDepth = 3; // an item = a subtree of up to 2^3 leaves
+
+// The parallel rounds of one wave.  `n_par` / `lev` / control points: this lane's command (n_par = 0: it takes no
+// part).  point(owner lane, index of the point inside its command, x, y) is called once per point, in order inside
+// an item; done(owner lane) after the last point of an item.
+template <class Point, class Done>
+__device__ __forceinline__ void wave_parallel_points(WaveQuads &w, uint32_t lane, uint32_t n_par, uint32_t lev, double sx, double sy,
+                                                     double cx, double cy, double ex, double ey, Point point, Done done)
+{
+	const uint32_t n_items = n_par == 0 ? 0u : (n_par > (1u << kItemDepth) ? n_par >> kItemDepth : 1u);
+	uint32_t total;
+	const uint32_t excl = wave_exclusive_sum(n_items, total);
+	w.pre[lane] = excl;
+	if (lane == 0)
+		w.pre[64] = total;
+	w.lev[lane] = lev;
+	w.sx[lane] = sx, w.sy[lane] = sy, w.cx[lane] = cx, w.cy[lane] = cy, w.ex[lane] = ex, w.ey[lane] = ey;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	for (uint32_t q = lane; q < total; q += 64) {
+		uint32_t k = 0; // the last command with pre[k] <= q (commands without items share their successor's offset)
+#pragma unroll
+		for (uint32_t step = 32; step > 0; step >>= 1)
+			if (w.pre[k + step] <= q)
+				k += step;
+		const uint32_t L = w.lev[k], item = q - w.pre[k];
+		const uint32_t Db = L < kItemDepth ? L : kItemDepth;
+		double qsx = w.sx[k], qsy = w.sy[k], qcx = w.cx[k], qcy = w.cy[k], qex = w.ex[k], qey = w.ey[k];
+		// down to the item's root: the bits of `item`, most significant first
+		for (uint32_t l = L - Db; l-- > 0;) {
+			const double m1x = (qsx + qcx) / 2.0, m1y = (qsy + qcy) / 2.0; // point.rs:29-31
+			const double m2x = (qcx + qex) / 2.0, m2y = (qcy + qey) / 2.0;
+			const double mx = (m1x + m2x) / 2.0, my = (m1y + m2y) / 2.0;
+			if ((item >> l) & 1u) { // right half (m, m2, e)
+				qsx = mx, qsy = my, qcx = m2x, qcy = m2y;
+			} else { // left half (s, m1, m)
+				qcx = m1x, qcy = m1y, qex = mx, qey = my;
+			}
+		}
+		uint32_t j = item << Db;
+		auto emit = [&](double x, double y) {
+			point(k, j, x, y);
+			j++;
+		};
+		if (Db == 3)
+			quad_subtree<3>(qsx, qsy, qcx, qcy, qex, qey, emit);
+		else if (Db == 0)
+			quad_subtree<0>(qsx, qsy, qcx, qcy, qex, qey, emit);
+		else if (Db == 2)
+			quad_subtree<2>(qsx, qsy, qcx, qcy, qex, qey, emit);
+		else
+			quad_subtree<1>(qsx, qsy, qcx, qcy, qex, qey, emit);
+		done(k);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// f64 <-> unsigned key with the same order (for integer atomics on LDS)
+__device__ __forceinline__ unsigned long long f64_key(double v)
+{
+	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k)
+{
+	return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+
+// ---------------------------------------------------------------------------------------
 // context: one wave per glyph.  Is the ring non-empty when command c arrives?  (quad_to / curve_to are ignored
 // on an empty ring, ring_builder.rs:83-85,99-101.)
 // ---------------------------------------------------------------------------------------
@@ -265,7 +387,7 @@ __global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restri
 	}
 }
 
-constexpr int kFlattenThreads = 64; // one wave per workgroup: 16 KiB of LDS stack each, 9 workgroups per CU
+constexpr int kFlattenThreads = 64; // one wave per workgroup
 
 // ---------------------------------------------------------------------------------------
 // count: thread per command — the first flattening pass (ring.rs:119-187).  Stores the number of points the
@@ -280,45 +402,96 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_count(const OutlineCm
                                                                  const double *__restrict__ shift_x,
                                                                  uint32_t *__restrict__ counts, double4 *__restrict__ cmd_box)
 {
-	__shared__ double s_stack[4 * kLdsLevels * 64];
+	__shared__ double s_stack[kSerialStackDoubles];
+	__shared__ WaveQuads s_w;
+	__shared__ unsigned long long s_box[4][64]; // per command: min x, min y (keys), max x, max y
+	const uint32_t lane = threadIdx.x;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_cmds)
-		return;
-	const OutlineCmd cmd = cmds[i];
-	const uint8_t ctx = cmd_open[i];
+	const bool valid = i < n_cmds;
+	OutlineCmd cmd;
+	cmd.kind = CMD_CLOSE;
+	cmd.x = cmd.y = cmd.x1 = cmd.y1 = cmd.x2 = cmd.y2 = 0.0f;
+	uint8_t ctx = 0;
+	if (valid) {
+		cmd = cmds[i];
+		ctx = cmd_open[i];
+	}
 	const bool open = (ctx & 1) != 0;
 	// when the ring is open the previous command of the glyph emitted at least one point and ended on its own
 	// (x, y): that is the current point of the ring
 	const double lx = open ? (double)cmds[i - 1].x : 0.0, ly = open ? (double)cmds[i - 1].y : 0.0;
 	const double inf = __builtin_huge_val();
-	double minx = inf, miny = inf, maxx = -inf, maxy = -inf;
 	const bool raw_boxes = (ctx & 2) == 0;
-	double sc = 1.0, dx = 0.0;
-	if (!raw_boxes) { // rare: find the glyph (last g with cmd_off[g] <= i) for its scale and shift
-		uint32_t lo = 0, hi = n_glyphs;
-		while (hi - lo > 1) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if (cmd_off[mid] <= i)
-				lo = mid;
-			else
-				hi = mid;
-		}
-		sc = scale[lo];
-		dx = shift_x[lo];
+	// parallel rounds: move_to / line_to (one point, a tree of depth 0) and the quadratics with a complete tree
+	uint32_t n_par = 0, lev = 0;
+	if (valid && raw_boxes) {
+		if (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE)
+			n_par = 1;
+		else if (cmd.kind == CMD_QUAD && open)
+			n_par = quad_parallel_points(lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y, lev);
 	}
-	counts[i] = run_command(cmd, open, lx, ly, s_stack + threadIdx.x, [&](double x, double y) {
-		if (!raw_boxes) {
-			x *= sc;
-			y *= sc;
-			x += dx;
-			y += 0.0;
+	s_box[0][lane] = s_box[1][lane] = f64_key(inf);
+	s_box[2][lane] = s_box[3][lane] = f64_key(-inf);
+	{
+		double bx0 = inf, by0 = inf, bx1 = -inf, by1 = -inf; // box of the item being walked
+		wave_parallel_points(
+		    s_w, lane, n_par, lev, lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y,
+		    [&](uint32_t, uint32_t, double x, double y) {
+			    bx0 = fmin(bx0, x); // bbox.rs:64-69 (fmin / fmax skip NaN)
+			    by0 = fmin(by0, y);
+			    bx1 = fmax(bx1, x);
+			    by1 = fmax(by1, y);
+		    },
+		    [&](uint32_t k) {
+			    atomicMin(&s_box[0][k], f64_key(bx0));
+			    atomicMin(&s_box[1][k], f64_key(by0));
+			    atomicMax(&s_box[2][k], f64_key(bx1));
+			    atomicMax(&s_box[3][k], f64_key(by1));
+			    bx0 = inf, by0 = inf, bx1 = -inf, by1 = -inf;
+		    });
+	}
+	if (valid && n_par != 0) {
+		counts[i] = n_par;
+		cmd_box[i] = make_double4(key_f64(s_box[0][lane]), key_f64(s_box[1][lane]), key_f64(s_box[2][lane]), key_f64(s_box[3][lane]));
+	}
+	// sequential walks, one lane at a time (they share the wave's work list in LDS); quad_to / curve_to on an empty
+	// ring and close() append nothing and need no walk
+	const bool walk = valid && n_par == 0 && (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE || ((cmd.kind == CMD_QUAD || cmd.kind == CMD_CURVE) && open));
+	if (valid && n_par == 0 && !walk) {
+		counts[i] = 0;
+		cmd_box[i] = make_double4(inf, inf, -inf, -inf);
+	}
+	for (unsigned long long todo = __ballot(walk); todo; todo &= todo - 1) {
+		if (lane != (uint32_t)__builtin_ctzll(todo))
+			continue;
+		double minx = inf, miny = inf, maxx = -inf, maxy = -inf;
+		double sc = 1.0, dx = 0.0;
+		if (!raw_boxes) { // rare: find the glyph (last g with cmd_off[g] <= i) for its scale and shift
+			uint32_t lo = 0, hi = n_glyphs;
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (cmd_off[mid] <= i)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			sc = scale[lo];
+			dx = shift_x[lo];
 		}
-		minx = fmin(minx, x); // bbox.rs:64-69 (fmin / fmax skip NaN)
-		miny = fmin(miny, y);
-		maxx = fmax(maxx, x);
-		maxy = fmax(maxy, y);
-	});
-	cmd_box[i] = make_double4(minx, miny, maxx, maxy);
+		counts[i] = run_command(cmd, open, lx, ly, s_stack, [&](double x, double y) {
+			if (!raw_boxes) {
+				x *= sc;
+				y *= sc;
+				x += dx;
+				y += 0.0;
+			}
+			minx = fmin(minx, x); // bbox.rs:64-69 (fmin / fmax skip NaN)
+			miny = fmin(miny, y);
+			maxx = fmax(maxx, x);
+			maxy = fmax(maxy, y);
+		});
+		cmd_box[i] = make_double4(minx, miny, maxx, maxy);
+	}
 }
 
 // ---------------------------------------------------------------------------------------
@@ -677,6 +850,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 // ring open in front of it unless it opened the ring itself (move_to / line_to, which do not care).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const OutlineCmd *__restrict__ cmds, uint32_t n_cmds,
+                                                                         const uint8_t *__restrict__ cmd_open,
                                                                          const double *__restrict__ scale,
                                                                          const double *__restrict__ shift_x,
                                                                          const uint32_t *__restrict__ pt_local,
@@ -686,42 +860,97 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
                                                                          const PlanHeader *__restrict__ hdr,
                                                                          unsigned long long seg_cap, double2 *__restrict__ seg)
 {
-	__shared__ double s_stack[4 * kLdsLevels * 64];
-	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= n_cmds)
-		return;
+	__shared__ double s_stack[kSerialStackDoubles];
+	__shared__ WaveQuads s_w;
+	// per command, for the lanes that place its points: first record of its ring, index of its first point inside
+	// the ring, the ring's point count and closing flag, the glyph's transform
+	__shared__ unsigned long long s_seg0[64];
+	__shared__ uint32_t s_idx0[64], s_n[64], s_append[64];
+	__shared__ double s_sc[64], s_dx[64];
 	if (hdr->error || hdr->n_segments > seg_cap) // nothing may be written: the host grows the arrays and launches again
 		return;
-	const uint32_t rcmd = cmd_ring[c];
-	if (rcmd == 0xFFFFFFFFu)
-		return;
-	const RingRec r = rings[rcmd];
-	if (!r.accepted)
-		return;
-	const GlyphDesc d = descs[r.glyph];
-	if (d.n_seg == 0) // PbfGlyph::empty (empty bbox): nothing is rasterised
-		return;
-	const OutlineCmd cmd = cmds[c];
-	const bool open = c != rcmd;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	bool active = c < n_cmds;
+	uint32_t rcmd = 0xFFFFFFFFu;
+	RingRec r;
+	r.accepted = 0, r.append = 0, r.pt_count = 0, r.pt_first = 0, r.seg_local = 0, r.glyph = 0;
+	GlyphDesc d;
+	d.n_seg = 0, d.seg_off = 0;
+	if (active) {
+		rcmd = cmd_ring[c];
+		active = rcmd != 0xFFFFFFFFu;
+	}
+	if (active) {
+		r = rings[rcmd];
+		active = r.accepted != 0;
+	}
+	if (active) {
+		d = descs[r.glyph];
+		active = d.n_seg != 0; // else PbfGlyph::empty (empty bbox): nothing is rasterised
+	}
+	OutlineCmd cmd;
+	cmd.kind = CMD_CLOSE;
+	cmd.x = cmd.y = cmd.x1 = cmd.y1 = cmd.x2 = cmd.y2 = 0.0f;
+	double sc = 1.0, dx = 0.0;
+	uint32_t idx = 0;
+	bool monotone = false;
+	if (active) {
+		cmd = cmds[c];
+		sc = scale[r.glyph], dx = shift_x[r.glyph];
+		idx = pt_local[c + r.glyph] - r.pt_first; // position of the command's first point inside its ring
+		monotone = (cmd_open[c] & 2) == 0;       // (the count pass took the sequential walk for the other glyphs)
+	}
+	const bool open = active && c != rcmd;
 	const double lx = open ? (double)cmds[c - 1].x : 0.0, ly = open ? (double)cmds[c - 1].y : 0.0;
-	const double sc = scale[r.glyph], dx = shift_x[r.glyph];
-	uint32_t idx = pt_local[c + r.glyph] - r.pt_first; // position of the command's first point inside its ring
 	const size_t seg0 = (size_t)d.seg_off + r.seg_local;
-	const uint32_t n = r.pt_count, last_seg = n - 1; // segment n - 1 exists only with the appended point
-	run_command(cmd, open, lx, ly, s_stack + threadIdx.x, [&](double x, double y) {
-		x *= sc; // point.rs:96-99
-		y *= sc;
-		x += dx; // point.rs:83-86
-		y += 0.0;
+	// point `at` of a ring of n points (scaled + shifted): start of segment `at`, end of segment `at - 1`
+	auto place = [&](size_t base, uint32_t at, uint32_t n, uint32_t append, double x, double y) {
 		// records {sx, sy, ex, ey}: two 16-byte stores per point, side by side in memory
-		if (idx + 1 < n || r.append) // start of segment idx
-			seg[2 * (seg0 + idx)] = make_double2(x, y);
-		if (idx >= 1) // end of segment idx - 1
-			seg[2 * (seg0 + idx - 1) + 1] = make_double2(x, y);
-		else if (r.append) // the closing segment returns to the first point
-			seg[2 * (seg0 + last_seg) + 1] = make_double2(x, y);
-		idx++;
-	});
+		if (at + 1 < n || append) // start of segment at
+			seg[2 * (base + at)] = make_double2(x, y);
+		if (at >= 1) // end of segment at - 1
+			seg[2 * (base + at - 1) + 1] = make_double2(x, y);
+		else if (append) // the closing segment (n - 1) returns to the first point
+			seg[2 * (base + n - 1) + 1] = make_double2(x, y);
+	};
+	uint32_t n_par = 0, lev = 0;
+	if (active && monotone) { // the same split as in the count pass
+		if (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE)
+			n_par = 1;
+		else if (cmd.kind == CMD_QUAD && open)
+			n_par = quad_parallel_points(lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y, lev);
+	}
+	s_seg0[lane] = (unsigned long long)seg0;
+	s_idx0[lane] = idx;
+	s_n[lane] = r.pt_count;
+	s_append[lane] = r.append;
+	s_sc[lane] = sc;
+	s_dx[lane] = dx;
+	wave_parallel_points(s_w, lane, n_par, lev, lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y,
+	                     [&](uint32_t k, uint32_t j, double x, double y) {
+		                     const double ksc = s_sc[k];
+		                     x *= ksc; // point.rs:96-99
+		                     y *= ksc;
+		                     x += s_dx[k]; // point.rs:83-86
+		                     y += 0.0;
+		                     place((size_t)s_seg0[k], s_idx0[k] + j, s_n[k], s_append[k], x, y);
+	                     },
+	                     [](uint32_t) {});
+	// sequential walks, one lane at a time (they share the wave's work list in LDS)
+	const bool walk = active && n_par == 0 && (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE || ((cmd.kind == CMD_QUAD || cmd.kind == CMD_CURVE) && open));
+	for (unsigned long long todo = __ballot(walk); todo; todo &= todo - 1) {
+		if (lane != (uint32_t)__builtin_ctzll(todo))
+			continue;
+		run_command(cmd, open, lx, ly, s_stack, [&](double x, double y) {
+			x *= sc; // point.rs:96-99
+			y *= sc;
+			x += dx; // point.rs:83-86
+			y += 0.0;
+			place(seg0, idx, r.pt_count, r.append, x, y);
+			idx++;
+		});
+	}
 }
 
 } // namespace vgsdf
@@ -769,7 +998,8 @@ extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, i
 	return (int)hipGetLastError();
 }
 
-extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cmds, const double *scale, const double *shift_x,
+extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cmds, const uint8_t *cmd_open, const double *scale,
+                                           const double *shift_x,
                                            const uint32_t *pt_local, const RingRec *rings, const uint32_t *cmd_ring,
                                            const GlyphDesc *descs, const PlanHeader *hdr, unsigned long long seg_cap, double *seg,
                                            hipStream_t stream)
@@ -777,6 +1007,6 @@ extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cm
 	if (n_cmds == 0)
 		return 0;
 	hipLaunchKernelGGL(outline_emit_segments, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream,
-	                   cmds, n_cmds, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg);
+	                   cmds, n_cmds, cmd_open, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg);
 	return (int)hipGetLastError();
 }

@@ -863,7 +863,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		                          (const uint32_t *)fe.flag.p, st);
 	};
 	auto launch_emit = [&]() -> int {
-		int e = vgsdf_outline_emit_segments(d_cmds, n_cmds, d_scale, d_shift, (const uint32_t *)fe.pt_local.p,
+		int e = vgsdf_outline_emit_segments(d_cmds, n_cmds, (const uint8_t *)fe.cmd_open.p, d_scale, d_shift, (const uint32_t *)fe.pt_local.p,
 		                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d_descs, d_hdr,
 		                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, st);
 		if (e == 0 && span)
