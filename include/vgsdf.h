@@ -151,6 +151,15 @@ typedef struct {
 int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
                            uint64_t *n_segments);
 int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps);
+/* prepare + render as ONE submission: the raster is enqueued right behind the front-end kernels, before the host
+ * has seen the sizes; the device checks the grid and every capacity it was launched against.  `out_bitmaps` holds
+ * `out_capacity` bytes (from earlier batches, or a guess).  If it comes from vgsdf_host_alloc() the raster writes
+ * the bitmaps straight into it (no copy, one synchronisation per call).  On return *out_bytes is the size needed;
+ * *rendered = 1: the bitmaps are in out_bitmaps (packed in glyph order, as vgsdf_outlines_render leaves them);
+ * *rendered = 0 (only when *out_bytes > out_capacity): the batch stays prepared — grow the buffer and call
+ * vgsdf_outlines_render().  Results are identical to prepare + render. */
+int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint8_t *out_bitmaps,
+                               size_t out_capacity, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
 /* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */
 int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey);
 

@@ -80,6 +80,28 @@ def test_bitmaps_through_front_end(oracle, vg, ctx, fira_oracle):
     assert off == out_bytes
 
 
+def test_one_submission_form_equals_prepare_plus_render(vg, fira_oracle):
+    """vgsdf_outlines_render_into: the raster is enqueued behind the front-end with guessed sizes; whatever the
+    guesses (fresh context, batches growing and shrinking, capacity too small, page-locked or pageable destination)
+    the rects and bitmaps are those of prepare + render."""
+    ref_ctx = vg.SdfContext(0)
+    ctx2 = vg.SdfContext(0)
+    for lo, hi in [(0x20, 0x60), (0x20, 0x400), (0x41, 0x48), (0x100, 0x180), (0x20, 0x2000)]:
+        cmd_off, cmds, scale, shift, ids = record(vg, fira_oracle, range(lo, hi))
+        rects, out_bytes, n_seg = ref_ctx.outlines_prepare(cmd_off, cmds, scale, shift)
+        want = ref_ctx.outlines_render()
+        for pinned in (True, False):
+            r2, out, ob, ns = ctx2.outlines_render_into(cmd_off, cmds, scale, shift, out_bytes + 1000, pinned=pinned)
+            assert (ob, ns) == (out_bytes, n_seg) and r2.tobytes() == rects.tobytes()
+            assert out is not None and out.tobytes() == want.tobytes(), (lo, hi, pinned)
+        if out_bytes > 1:  # too small: nothing rendered, the batch stays prepared
+            r2, out, ob, ns = ctx2.outlines_render_into(cmd_off, cmds, scale, shift, out_bytes - 1)
+            assert out is None and ob == out_bytes and r2.tobytes() == rects.tobytes()
+            assert ctx2.outlines_render().tobytes() == want.tobytes()
+    ref_ctx.close()
+    ctx2.close()
+
+
 def test_arbitrary_command_streams(oracle, vg, ctx):
     # streams ttf-parser never emits: curve_to, quad_to on an empty ring, line_to starting a
     # ring, missing close, degenerate rings, repeated closes; rings via the oracle's RingBuilder

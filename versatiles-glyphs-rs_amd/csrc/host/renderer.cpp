@@ -253,11 +253,18 @@ void Renderer::render_outlines(const vgsdf_outlines &v, std::vector<vgsdf_rect> 
 	if (mode_ != Mode::Hip)
 		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
 	std::lock_guard<std::mutex> lock(mu_);
-	if (vgsdf_outlines_prepare(ctx_, &v, rects.data(), &out_bytes, &n_segments) != VGSDF_OK)
-		throw std::runtime_error(std::string("vgsdf_outlines_prepare: ") + vgsdf_last_error(ctx_));
-	out.ensure((size_t)out_bytes + 1);
-	if (vgsdf_outlines_render(ctx_, out.data()) != VGSDF_OK)
-		throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(ctx_));
+	// one submission: the raster writes into `out` as it stands (capacity kept from earlier groups; first guess
+	// 448 bytes per glyph, the average of the fixture fonts) — a second step only when that was too small
+	if (out.capacity() == 0)
+		out.ensure((size_t)v.n_glyphs * 448 + 4096);
+	int rendered = 0;
+	if (vgsdf_outlines_render_into(ctx_, &v, rects.data(), out.data(), out.capacity(), &out_bytes, &n_segments, &rendered) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_outlines_render_into: ") + vgsdf_last_error(ctx_));
+	if (!rendered) {
+		out.ensure((size_t)out_bytes + 1);
+		if (vgsdf_outlines_render(ctx_, out.data()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(ctx_));
+	}
 }
 
 void Renderer::render_batch(const GlyphBatch &batch, uint8_t *out) const

@@ -105,6 +105,7 @@ public:
 	}
 	T *data() { return p_; }
 	const T *data() const { return p_; }
+	size_t capacity() const { return cap_; }
 	T &operator[](size_t i) { return p_[i]; }
 	const T &operator[](size_t i) const { return p_[i]; }
 

@@ -42,7 +42,8 @@ struct PlanHeader {
 	uint32_t n_spans;              // entries of the work list (may exceed the capacity it was planned with)
 	uint32_t n_main;               // of which for the main kernel (they come first)
 	uint32_t error;                // != 0: absurd input (a glyph beyond 2^28 points / 2^32 pixels, more than 2^32 - 1 segments)
-	uint32_t pad;
+	uint32_t ok;                   // the raster launch enqueued behind the plan may run: no error, everything within the
+	                               // capacities and the grid it was planned against (outline_plan's last arguments)
 };
 
 struct GlyphDesc;
@@ -62,9 +63,12 @@ int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, 
                         const double *shift_x, uint32_t n_glyphs, const uint32_t *counts, uint32_t *pt_local, const void *cmd_box,
                         vgsdf::RingRec *rings, uint32_t *cmd_ring, vgsdf::OutlineRect *rects, uint32_t *error_flag,
                         hipStream_t stream);
+// seg_cap / out_cap / launch_spans: what PlanHeader::ok is decided against (capacity of the segment records, of the
+// output buffer, grid of the raster launch enqueued behind the plan; launch_spans = 0: no such launch)
 int vgsdf_outline_plan(const vgsdf::OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
                        uint32_t span_budget, uint32_t tile_cap, vgsdf::GlyphDesc *descs, uint2 *tiles, vgsdf::PlanHeader *hdr,
-                       const uint32_t *error_flag, hipStream_t stream);
+                       const uint32_t *error_flag, unsigned long long seg_cap, unsigned long long out_cap, uint32_t launch_spans,
+                       hipStream_t stream);
 int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const uint8_t *cmd_open, const double *scale,
                                 const double *shift_x,
                                 const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,

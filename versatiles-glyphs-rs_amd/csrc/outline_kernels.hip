@@ -714,7 +714,8 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
                                                              uint32_t delta_cap, uint32_t span_max, uint32_t span_budget,
                                                              uint32_t tile_cap, GlyphDesc *__restrict__ descs,
                                                              uint2 *__restrict__ tiles, PlanHeader *__restrict__ hdr,
-                                                             const uint32_t *__restrict__ error_flag)
+                                                             const uint32_t *__restrict__ error_flag, unsigned long long seg_cap,
+                                                             unsigned long long out_cap, uint32_t launch_spans)
 {
 	__shared__ unsigned long long s_wave[kPlanThreads / 64 + 1];
 	__shared__ uint32_t s_hist[2][kPlanBuckets]; // spans per (class, bucket); then the bucket's write cursor
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 		hdr->n_spans = s_nall;
 		hdr->n_main = s_nmain;
 		hdr->error = (error_flag[0] != 0) || (s_carry[0] > 0xFFFFFFFFull) || (acc > 0x7FFFFFFFull);
-		hdr->pad = 0;
+		hdr->ok = 0;
 	}
 	__syncthreads();
 	const bool any_bad = __syncthreads_or(bad);
@@ -824,6 +825,9 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	// grows it and runs the plan again
 	if (any_bad || error_flag[0] != 0 || s_carry[0] > 0xFFFFFFFFull || s_nall > tile_cap || s_nall > 0x7FFFFFFFu)
 		return;
+	// (every glyph's entries are in place when the kernel ends: a launch enqueued behind it may read the list)
+	if (tid == 0)
+		hdr->ok = s_carry[0] <= seg_cap && s_carry[1] <= out_cap && s_nall == s_nmain && s_nmain <= launch_spans;
 	// pass B: entries.  One per span of T tiles: (glyph, first pixel | T) in the span list's main class, else
 	// (glyph, first pixel).
 	for (uint32_t g = tid; g < n_glyphs; g += kPlanThreads) {
@@ -991,10 +995,11 @@ extern "C" int vgsdf_outline_rings(const OutlineCmd *cmds, const uint32_t *cmd_o
 
 extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
                                   uint32_t span_budget, uint32_t tile_cap, GlyphDesc *descs, uint2 *tiles, PlanHeader *hdr,
-                                  const uint32_t *error_flag, hipStream_t stream)
+                                  const uint32_t *error_flag, unsigned long long seg_cap, unsigned long long out_cap,
+                                  uint32_t launch_spans, hipStream_t stream)
 {
 	hipLaunchKernelGGL(outline_plan, dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
-	                   span_budget, tile_cap, descs, tiles, hdr, error_flag);
+	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans);
 	return (int)hipGetLastError();
 }
 

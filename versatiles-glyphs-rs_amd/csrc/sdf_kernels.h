@@ -36,6 +36,11 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
                                   const double *sy, const double *ex, const double *ey, uint32_t seg_stride,
                                   uint8_t *out, const void *boxes, hipStream_t stream);
 
+// the span kernel over a device-planned work list that may still be in the making when the launch is enqueued (see .hip)
+extern "C" int vgsdf_launch_span_planned(const vgsdf::GlyphDesc *glyphs, const uint2 *tiles, uint32_t grid, const double *sx,
+                                         const double *sy, const double *ex, const double *ey, uint32_t seg_stride, uint8_t *out,
+                                         const void *boxes, const void *plan, hipStream_t stream);
+
 // chunk boxes of a resident batch (sdf_chunk_boxes): table size, and the preparation launch.  `boxes`
 // may be NULL in vgsdf_launch_tiles (no chunk is skipped then); only the span kernel reads it.
 extern "C" size_t vgsdf_chunk_box_bytes(uint64_t n_segments, uint32_t n_glyphs);

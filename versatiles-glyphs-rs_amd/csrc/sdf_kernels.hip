@@ -283,8 +283,12 @@ __global__ __launch_bounds__(TPB, 4) void sdf_tiles_span(const GlyphDesc *__rest
                                                       const double *__restrict__ seg_ex,
                                                       const double *__restrict__ seg_ey, uint32_t seg_stride,
                                                       uint8_t *__restrict__ out, const float4 *__restrict__ boxes,
-                                                      unsigned long long *__restrict__ dbg)
+                                                      unsigned long long *__restrict__ dbg, const PlanHeader *__restrict__ plan)
 {
+	// Behind the device front-end the launch is enqueued before the host has seen the plan: the grid is a guess
+	// (>= the work list, or the plan says "not ok": some capacity was too small and the host launches again)
+	if (plan != nullptr && (!plan->ok || blockIdx.x >= plan->n_main))
+		return;
 	// ABL & 256 (development builds): s_memtime stamps per phase, summed per wave into dbg[region]
 	// (cdna_hip_programming.md, "In-kernel stamps"); read the SHARES, never this build's run time.
 	unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
@@ -851,6 +855,19 @@ extern "C" int vgsdf_launch_chunk_boxes(const vgsdf::GlyphDesc *glyphs, uint32_t
 	return (int)hipGetLastError();
 }
 
+// The span kernel over a work list that outline_plan is still writing when this is enqueued: `grid` workgroups
+// (a guess >= plan->n_main, else plan->ok is 0 and nothing runs), list order.
+extern "C" int vgsdf_launch_span_planned(const vgsdf::GlyphDesc *glyphs, const uint2 *tiles, uint32_t grid, const double *sx,
+                                         const double *sy, const double *ex, const double *ey, uint32_t seg_stride, uint8_t *out,
+                                         const void *boxes, const void *plan, hipStream_t stream)
+{
+	if (grid == 0)
+		return 0;
+	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<0>), dim3(grid), dim3(vgsdf::TPB), 0, stream, glyphs, tiles, grid | 0x80000000u, sx, sy,
+	                   ex, ey, seg_stride, out, (const float4 *)boxes, (unsigned long long *)nullptr, (const vgsdf::PlanHeader *)plan);
+	return (int)hipGetLastError();
+}
+
 // kernel ids: 50 = the bounded-group span kernel (public variant 0), 1 = brute force, also the fallback
 // for the tiles the host routes there: glyphs too wide for the winding histogram, or with >= 2^24
 // segments.  Everything else exists only in development builds (-DVGSDF_DEV_VARIANTS).
@@ -877,7 +894,8 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 	const uint32_t n_tiles = n_tiles_in | (list_order ? 0x80000000u : 0u);
 #define VG_LAUNCH_SPAN(A)                                                                                 \
 	hipLaunchKernelGGL((vgsdf::sdf_tiles_span<A>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles,   \
-	                   sx, sy, ex, ey, seg_stride, out, (const float4 *)boxes, (unsigned long long *)nullptr)
+	                   sx, sy, ex, ey, seg_stride, out, (const float4 *)boxes, (unsigned long long *)nullptr,                \
+	                   (const vgsdf::PlanHeader *)nullptr)
 	if (variant == 1)
 		hipLaunchKernelGGL(vgsdf::sdf_tiles_brute, grid, dim3(vgsdf::TPB), 0, stream, glyphs,
 		                   tiles, n_tiles, sx, sy, ex, ey, seg_stride, out);
@@ -920,7 +938,7 @@ extern "C" int vgsdf_launch_tiles(int variant, int list_order, const vgsdf::Glyp
 			return (int)hipErrorOutOfMemory;
 		(void)hipMemsetAsync(d_dbg, 0, 24 * sizeof(unsigned long long), stream);
 		hipLaunchKernelGGL((vgsdf::sdf_tiles_span<256>), grid, dim3(vgsdf::TPB), 0, stream, glyphs, tiles, n_tiles, sx, sy, ex,
-		                   ey, seg_stride, out, (const float4 *)boxes, d_dbg);
+		                   ey, seg_stride, out, (const float4 *)boxes, d_dbg, (const vgsdf::PlanHeader *)nullptr);
 		unsigned long long h[24];
 		(void)hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream);
 		(void)hipStreamSynchronize(stream);

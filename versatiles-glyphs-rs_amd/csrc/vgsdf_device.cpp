@@ -108,6 +108,7 @@ struct FrontEnd {
 	DevBuf seg, out, boxes; // seg: records {sx, sy, ex, ey}
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
+	uint32_t last_spans = 0;          // work-list length of the previous batch (grid guess of the one-submission form)
 	uint32_t n_glyphs = 0, n_cmds = 0, n_segs = 0;
 	uint64_t out_bytes = 0;
 	vgsdf_dbatch batch; // borrowed view over the buffers above
@@ -738,10 +739,17 @@ int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitma
 		}                                                                                       \
 	} while (0)
 
-int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
-                           uint64_t *n_segments)
+// prepare, and — with a destination (`spec_out`, `spec_cap` bytes) — the raster enqueued right behind the front-end,
+// before the host has seen the plan: its grid and every capacity are guesses the plan kernel checks on the device
+// (PlanHeader::ok).  When they hold, the bitmaps are in `spec_out` after the ONE synchronisation of the call
+// (written there by the kernel itself if the buffer is page-locked); when not, the usual second launches run.
+// *rendered: the bitmaps are in spec_out.
+static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments,
+                      uint8_t *spec_out, size_t spec_cap, int *rendered)
 {
 	static const bool trace = std::getenv("VGSDF_TRACE") != nullptr;
+	if (rendered)
+		*rendered = 0;
 	const double tr0 = fe_now();
 	double tr1 = 0, tr2 = 0, tr3 = 0;
 	if (!ctx)
@@ -857,10 +865,26 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	const uint32_t span_max = sm ? (uint32_t)std::min(4, std::max(1, std::atoi(sm))) : 4u;
 	const char *sb = std::getenv("VGSDF_SPAN_BUDGET");
 	const uint32_t span_budget = sb ? (uint32_t)std::max(1, std::atoi(sb)) : 16u;
-	auto launch_plan = [&]() {
+	// the raster launch enqueued behind the front-end (one-submission form): default kernel only, destination the
+	// caller's page-locked buffer itself or, for pageable memory, the context's device buffer
+	const bool spec = spec_out != nullptr && spec_cap != 0 && ctx->variant == 0;
+	uint8_t *d_spec = nullptr;
+	uint32_t launch_spans = 0;
+	if (spec) {
+		if (is_pinned(spec_out, spec_cap)) {
+			d_spec = spec_out;
+		} else {
+			FE_TRY(fe.out.ensure(spec_cap + 16));
+			d_spec = (uint8_t *)fe.out.p;
+		}
+		const size_t guess = fe.last_spans ? (size_t)fe.last_spans + fe.last_spans / 2 + 256 : fe.tile_cap;
+		launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
+	}
+	auto launch_plan = [&](uint32_t spans_launched) {
 		return vgsdf_outline_plan(d_rects, n, span ? 1 : 0, (uint32_t)vgsdf_filtered_delta_cap(), span_max, span_budget,
 		                          (uint32_t)std::min<size_t>(fe.tile_cap, 0x7FFFFFFFu), d_descs, (uint2 *)fe.tiles.p, d_hdr,
-		                          (const uint32_t *)fe.flag.p, st);
+		                          (const uint32_t *)fe.flag.p, (unsigned long long)fe.seg_cap, (unsigned long long)spec_cap,
+		                          spans_launched, st);
 	};
 	auto launch_emit = [&]() -> int {
 		int e = vgsdf_outline_emit_segments(d_cmds, n_cmds, (const uint8_t *)fe.cmd_open.p, d_scale, d_shift, (const uint32_t *)fe.pt_local.p,
@@ -878,8 +902,12 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	                              (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_local.p,
 	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d_rects,
 	                              (uint32_t *)fe.flag.p, st));
-	FE_KERNEL(launch_plan());
+	FE_KERNEL(launch_plan(launch_spans));
 	FE_KERNEL(launch_emit());
+	if (spec)
+		FE_KERNEL(vgsdf_launch_span_planned(d_descs, (const uint2 *)fe.tiles.p, launch_spans, (const double *)fe.seg.p,
+		                                    (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2, (const double *)fe.seg.p + 3, 4,
+		                                    d_spec, fe.boxes.p, d_hdr, st));
 	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, rh_bytes, hipMemcpyDeviceToHost, st));
 	// (the command kinds are checked here, while the GPU works: the kernels treat an unknown kind as a no-op,
 	// so nothing unsafe runs before the check)
@@ -908,7 +936,7 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	const bool replan = hdr.n_spans > fe.tile_cap, reemit = hdr.n_segments > fe.seg_cap;
 	if (replan) {
 		FE_TRY(ensure_tiles((size_t)hdr.n_spans + hdr.n_spans / 4 + 1024));
-		FE_KERNEL(launch_plan());
+		FE_KERNEL(launch_plan(0));
 	}
 	if (reemit) {
 		FE_TRY(ensure_segs((size_t)hdr.n_segments + hdr.n_segments / 4 + 4096));
@@ -935,7 +963,10 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 	b.n_main = hdr.n_main;
 	b.span_list = span;
 	b.tile_order = 1; // the device-built list is dispatched in list order
-	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16));
+	fe.last_spans = hdr.n_spans;
+	const bool done = spec && hdr.ok != 0; // the raster behind the plan ran over the whole list
+	if (!(done && d_spec == spec_out))
+		FE_TRY(fe.out.ensure(std::max((size_t)fe.out_bytes, done ? spec_cap : (size_t)0) + 16));
 	b.d_glyphs = d_descs;
 	b.d_tiles = (uint2 *)fe.tiles.p;
 	b.d_sx = (double *)fe.seg.p;
@@ -950,11 +981,47 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		*out_bytes = fe.out_bytes;
 	if (n_segments)
 		*n_segments = fe.n_segs;
+	if (spec_out && fe.out_bytes <= spec_cap) {
+		int rc = VGSDF_OK;
+		if (done) {
+			if (d_spec != spec_out && fe.out_bytes) { // pageable destination: the raster wrote the device buffer
+				FE_TRY(hipMemcpyAsync(spec_out, d_spec, (size_t)fe.out_bytes, hipMemcpyDeviceToHost, st));
+				FE_TRY(hipStreamSynchronize(st));
+			}
+		} else if (fe.out_bytes) { // a guess was too small (first batch of a context, a batch unlike the last one)
+			rc = vgsdf_batch_launch(ctx, &fe.batch);
+			if (rc == VGSDF_OK)
+				rc = vgsdf_batch_download(ctx, &fe.batch, spec_out);
+		}
+		if (rc != VGSDF_OK)
+			return rc;
+		if (rendered)
+			*rendered = 1;
+	}
+	if (trace && spec_out)
+		std::fprintf(stderr, "[vgsdf] one submission%s, %s destination\n", done ? "" : " (guess too small: second launches)",
+		             d_spec == spec_out ? "page-locked" : "pageable");
 	if (trace)
 		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, upload + measure + plan + emit + read-back %.3f ms, second launches%s%s %.3f ms, host %.3f ms\n",
 		             (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, replan ? " (plan)" : "", reemit ? " (emit)" : "", (tr3 - tr2) * 1e3,
 		             (fe_now() - tr3) * 1e3);
 	return VGSDF_OK;
+}
+
+int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
+                           uint64_t *n_segments)
+{
+	return fe_prepare(ctx, in, rects_out, out_bytes, n_segments, nullptr, 0, nullptr);
+}
+
+int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint8_t *out_bitmaps,
+                               size_t out_capacity, uint64_t *out_bytes, uint64_t *n_segments, int *rendered)
+{
+	if (ctx && !rendered) {
+		ctx->err = "vgsdf_outlines_render_into: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	return fe_prepare(ctx, in, rects_out, out_bytes, n_segments, out_bitmaps, out_bitmaps ? out_capacity : 0, rendered);
 }
 
 int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps)
@@ -974,6 +1041,9 @@ int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps)
 	}
 	static const bool trace = std::getenv("VGSDF_TRACE") != nullptr;
 	const double t0 = fe_now();
+	(void)hipSetDevice(ctx->device);
+	FE_TRY(fe.out.ensure((size_t)fe.out_bytes + 16)); // (the one-submission form may have rendered elsewhere)
+	fe.batch.d_out = (uint8_t *)fe.out.p;
 	int rc = vgsdf_batch_launch(ctx, &fe.batch);
 	if (rc != VGSDF_OK)
 		return rc;

@@ -41,7 +41,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
-    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_segments",
+    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_segments",
 ]
 
 _lib = None
@@ -80,6 +80,7 @@ def load_library():
         L.vgsdf_host_free.restype = None
         L.vgsdf_outlines_prepare.argtypes = [vp, C.POINTER(_COutlines), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.vgsdf_outlines_render.argtypes = [vp, vp]
+        L.vgsdf_outlines_render_into.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -228,6 +229,32 @@ class SdfContext:
         self._check(load_library().vgsdf_outlines_prepare(self._h, C.byref(co), rects.ctypes.data, C.byref(ob), C.byref(ns)))
         self._fe = (n, int(ob.value), int(ns.value))
         return rects, int(ob.value), int(ns.value)
+
+    def outlines_render_into(self, cmd_off, cmds, scale, shift_x, capacity: int, pinned: bool = True):
+        """device front-end as ONE submission -> (rects, bitmaps | None, out_bytes, n_segments); bitmaps is None when
+        `capacity` bytes were too few (the batch stays prepared: outlines_render() finishes it)"""
+        L = load_library()
+        cmd_off = np.ascontiguousarray(cmd_off, dtype=np.uint32)
+        cmds = np.ascontiguousarray(cmds, dtype=OUTLINE_CMD_DTYPE)
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+        shift_x = np.ascontiguousarray(shift_x, dtype=np.float64)
+        n = len(scale)
+        rects = np.zeros(n, dtype=RECT_DTYPE)
+        ob, ns, done = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        co = _COutlines(n, cmd_off.ctypes.data, cmds.ctypes.data, scale.ctypes.data, shift_x.ctypes.data)
+        host = L.vgsdf_host_alloc(max(capacity, 1)) if pinned else None
+        if pinned and not host:
+            raise MemoryError("vgsdf_host_alloc")
+        try:
+            buf = (C.c_uint8 * max(capacity, 1)).from_address(host) if pinned else (C.c_uint8 * max(capacity, 1))()
+            self._check(L.vgsdf_outlines_render_into(self._h, C.byref(co), rects.ctypes.data, C.addressof(buf), capacity,
+                                                     C.byref(ob), C.byref(ns), C.byref(done)))
+            self._fe = (n, int(ob.value), int(ns.value))
+            out = np.frombuffer(buf, dtype=np.uint8, count=int(ob.value)).copy() if done.value else None
+        finally:
+            if pinned:
+                L.vgsdf_host_free(host)
+        return rects, out, int(ob.value), int(ns.value)
 
     def outlines_render(self) -> np.ndarray:
         """device front-end, step 2: bitmaps of the glyphs with a raster, packed in glyph order"""
