@@ -160,6 +160,13 @@ int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps);
  * vgsdf_outlines_render().  Results are identical to prepare + render. */
 int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint8_t *out_bitmaps,
                                size_t out_capacity, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
+/* The same in two halves, for callers that overlap their own work with the device (one batch in flight per context;
+ * use two contexts to keep the GPU busy while the host prepares the next batch and encodes the previous one):
+ * submit enqueues the upload, the front-end and the raster and returns at once; wait synchronises and reports as
+ * vgsdf_outlines_render_into does.  in->cmds and out_bitmaps must stay valid and untouched in between
+ * (out_bitmaps may be NULL: no raster is enqueued, wait then equals vgsdf_outlines_prepare). */
+int vgsdf_outlines_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *out_bitmaps, size_t out_capacity);
+int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
 /* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */
 int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey);
 

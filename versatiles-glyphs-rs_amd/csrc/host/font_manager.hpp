@@ -233,7 +233,7 @@ private:
 		uint64_t out_bytes = 0, n_segs = 0;
 		uint32_t n_jobs = 0;
 	};
-	FeGroup fe_group_;
+	FeGroup fe_group_[2]; // two groups in flight: one on the GPU, one being recorded / encoded
 	void fe_record(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off

@@ -147,6 +147,8 @@ std::shared_ptr<Renderer> Renderer::new_precise(int device, std::string *err)
 
 Renderer::~Renderer()
 {
+	if (ctx2_)
+		vgsdf_destroy(ctx2_);
 	if (ctx_)
 		vgsdf_destroy(ctx_);
 }
@@ -243,6 +245,62 @@ bool Renderer::record(const Face &face, uint32_t index, OutlineBatch &batch)
 	return true;
 }
 
+vgsdf_ctx *Renderer::lane_ctx(int lane) const
+{
+	if (lane == 0)
+		return ctx_;
+	std::lock_guard<std::mutex> lock(mu_);
+	if (!ctx2_ && vgsdf_create(device_, &ctx2_) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_create (second lane): ") + vgsdf_last_error(nullptr));
+	return ctx2_;
+}
+
+void Renderer::submit_outlines(int lane, const vgsdf_outlines &v, HostBuffer<uint8_t> &out) const
+{
+	if (mode_ != Mode::Hip)
+		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
+	lane &= 1;
+	vgsdf_ctx *c = lane_ctx(lane);
+	lane_mu_[lane].lock();
+	// one submission: the raster writes into `out` as it stands (capacity kept from earlier groups; first guess
+	// 448 bytes per glyph, the average of the fixture fonts) — a second step in wait only when that was too small
+	try {
+		if (out.capacity() == 0)
+			out.ensure((size_t)v.n_glyphs * 448 + 4096);
+		std::lock_guard<std::mutex> lock(mu_);
+		if (vgsdf_outlines_submit(c, &v, out.data(), out.capacity()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_submit: ") + vgsdf_last_error(c));
+	} catch (...) {
+		lane_mu_[lane].unlock();
+		throw;
+	}
+}
+
+void Renderer::wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
+                             uint64_t &n_segments, uint32_t n_glyphs) const
+{
+	lane &= 1;
+	vgsdf_ctx *c = lane == 0 ? ctx_ : ctx2_;
+	out_bytes = n_segments = 0;
+	struct Unlock {
+		std::mutex &m;
+		~Unlock() { m.unlock(); }
+	} unlock{lane_mu_[lane]};
+	rects.assign(n_glyphs, vgsdf_rect{});
+	int rendered = 0;
+	// lane 0 shares its context with the one-call entry points (render_batch, ...): keep them out while it is in use
+	std::unique_lock<std::mutex> lock(mu_, std::defer_lock);
+	if (lane == 0)
+		lock.lock();
+	if (vgsdf_outlines_wait(c, rects.data(), &out_bytes, &n_segments, &rendered) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_outlines_wait: ") + vgsdf_last_error(c));
+	if (!rendered && out_bytes) {
+		out.ensure((size_t)out_bytes + 1);
+		if (vgsdf_outlines_render(c, out.data()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(c));
+	}
+}
+
 void Renderer::render_outlines(const vgsdf_outlines &v, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
                                uint64_t &out_bytes, uint64_t &n_segments) const
 {
@@ -250,21 +308,8 @@ void Renderer::render_outlines(const vgsdf_outlines &v, std::vector<vgsdf_rect> 
 	out_bytes = n_segments = 0;
 	if (v.n_glyphs == 0)
 		return;
-	if (mode_ != Mode::Hip)
-		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
-	std::lock_guard<std::mutex> lock(mu_);
-	// one submission: the raster writes into `out` as it stands (capacity kept from earlier groups; first guess
-	// 448 bytes per glyph, the average of the fixture fonts) — a second step only when that was too small
-	if (out.capacity() == 0)
-		out.ensure((size_t)v.n_glyphs * 448 + 4096);
-	int rendered = 0;
-	if (vgsdf_outlines_render_into(ctx_, &v, rects.data(), out.data(), out.capacity(), &out_bytes, &n_segments, &rendered) != VGSDF_OK)
-		throw std::runtime_error(std::string("vgsdf_outlines_render_into: ") + vgsdf_last_error(ctx_));
-	if (!rendered) {
-		out.ensure((size_t)out_bytes + 1);
-		if (vgsdf_outlines_render(ctx_, out.data()) != VGSDF_OK)
-			throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(ctx_));
-	}
+	submit_outlines(0, v, out);
+	wait_outlines(0, rects, out, out_bytes, n_segments, v.n_glyphs);
 }
 
 void Renderer::render_batch(const GlyphBatch &batch, uint8_t *out) const

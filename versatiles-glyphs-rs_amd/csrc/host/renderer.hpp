@@ -246,6 +246,13 @@ public:
 	// the bitmaps of the glyphs that have a raster, packed in job order.  Hip mode only.
 	void render_outlines(const vgsdf_outlines &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
 	                     uint64_t &out_bytes, uint64_t &n_segments) const;
+	// The same in two halves on one of two lanes (each lane = its own device context and stream): submit enqueues
+	// upload, front-end and raster and returns; wait collects.  A caller that alternates the lanes keeps the GPU
+	// busy while it records the next batch and encodes the previous one.  `batch` (its command array) and `out`
+	// must stay untouched between the two calls; a lane is held from submit to wait.
+	void submit_outlines(int lane, const vgsdf_outlines &batch, HostBuffer<uint8_t> &out) const;
+	void wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
+	                   uint64_t &n_segments, uint32_t n_glyphs) const;
 
 	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one
 	// vgsdf_render_batch call; Dummy: zeros (renderer_dummy.rs).  Throws std::runtime_error.
@@ -265,6 +272,9 @@ private:
 	int device_ = 0;
 	vgsdf_ctx *ctx_ = nullptr;
 	mutable std::mutex mu_; // vgsdf_ctx is single-threaded
+	mutable vgsdf_ctx *ctx2_ = nullptr; // lane 1 of the two-deep pipeline (created on first use)
+	mutable std::mutex lane_mu_[2];     // held from submit_outlines to wait_outlines
+	vgsdf_ctx *lane_ctx(int lane) const;
 };
 
 } // namespace vg

@@ -41,7 +41,8 @@ struct PlanHeader {
 	unsigned long long out_bytes;  // sum of w * h
 	uint32_t n_spans;              // entries of the work list (may exceed the capacity it was planned with)
 	uint32_t n_main;               // of which for the main kernel (they come first)
-	uint32_t error;                // != 0: absurd input (a glyph beyond 2^28 points / 2^32 pixels, more than 2^32 - 1 segments)
+	uint32_t error;                // bit 0: absurd input (a glyph beyond 2^28 points / 2^32 pixels, more than 2^32 - 1 segments);
+	                               // bit 1: a command kind that is none of the five callbacks
 	uint32_t ok;                   // the raster launch enqueued behind the plan may run: no error, everything within the
 	                               // capacities and the grid it was planned against (outline_plan's last arguments)
 };
@@ -52,8 +53,9 @@ struct GlyphDesc;
 
 extern "C" {
 // cmd_open: one byte per command (bit 0: ring open in front of it, bit 1: the glyph's scale is not positive finite)
+// error_flag: one zeroed word; bit 1 is raised for a command kind that is none of the five callbacks
 int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
-                          uint8_t *cmd_open, hipStream_t stream);
+                          uint8_t *cmd_open, uint32_t *error_flag, hipStream_t stream);
 // counts: one per command; cmd_box: double4 per command
 int vgsdf_outline_count(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *cmd_off,
                         uint32_t n_glyphs, const double *scale, const double *shift_x, uint32_t *counts, void *cmd_box,

@@ -367,7 +367,7 @@ __device__ __forceinline__ double key_f64(unsigned long long k)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restrict__ cmds, const uint32_t *__restrict__ cmd_off,
                                                       const double *__restrict__ scale, uint32_t n_glyphs,
-                                                      uint8_t *__restrict__ cmd_open)
+                                                      uint8_t *__restrict__ cmd_open, uint32_t *__restrict__ error_flag)
 {
 	const uint32_t g = blockIdx.x, lane = threadIdx.x;
 	if (g >= n_glyphs)
@@ -382,8 +382,11 @@ __global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restri
 		const uint32_t c = base + lane;
 		const uint32_t k = c < c1 ? cmds[c].kind : 0xFFu;
 		const bool open = ring_open_before(k, lane, carry);
-		if (c < c1)
+		if (c < c1) {
 			cmd_open[c] = (uint8_t)((open ? 1 : 0) | odd);
+			if (k > CMD_CLOSE) // not one of the five callbacks: every kernel treats it as a no-op, the batch is refused
+				atomicOr(error_flag, 2u);
+		}
 	}
 }
 
@@ -814,13 +817,13 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 		hdr->out_bytes = s_carry[1];
 		hdr->n_spans = s_nall;
 		hdr->n_main = s_nmain;
-		hdr->error = (error_flag[0] != 0) || (s_carry[0] > 0xFFFFFFFFull) || (acc > 0x7FFFFFFFull);
+		hdr->error = error_flag[0] | (((s_carry[0] > 0xFFFFFFFFull) || (acc > 0x7FFFFFFFull)) ? 1u : 0u); // bit 0: sizes, bit 1: unknown command kind
 		hdr->ok = 0;
 	}
 	__syncthreads();
 	const bool any_bad = __syncthreads_or(bad);
 	if (tid == 0 && any_bad)
-		hdr->error = 1;
+		hdr->error |= 1u;
 	// no work list for a batch in error (its sizes may be absurd), nor when the list does not fit: the host
 	// grows it and runs the plan again
 	if (any_bad || error_flag[0] != 0 || s_carry[0] > 0xFFFFFFFFull || s_nall > tile_cap || s_nall > 0x7FFFFFFFu)
@@ -962,11 +965,11 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 using namespace vgsdf;
 
 extern "C" int vgsdf_outline_context(const OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
-                                     uint8_t *cmd_open, hipStream_t stream)
+                                     uint8_t *cmd_open, uint32_t *error_flag, hipStream_t stream)
 {
 	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(outline_context, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, scale, n_glyphs, cmd_open);
+	hipLaunchKernelGGL(outline_context, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, scale, n_glyphs, cmd_open, error_flag);
 	return (int)hipGetLastError();
 }
 

@@ -102,6 +102,18 @@ struct DevBuf {
 	}
 };
 
+// a submission between vgsdf_outlines_submit and vgsdf_outlines_wait
+struct FePending {
+	bool active = false;
+	uint32_t n = 0, n_cmds = 0;
+	size_t hdr_off = 0, rh_bytes = 0;
+	bool span = false, spec = false;
+	uint8_t *spec_out = nullptr, *d_spec = nullptr; // destination of the raster enqueued behind the front-end
+	size_t spec_cap = 0;
+	uint32_t launch_spans = 0, span_max = 4, span_budget = 16;
+	double t0 = 0, t1 = 0;
+};
+
 struct FrontEnd {
 	// device: inputs, per-command / per-ring intermediates, results of measure + plan, the resident batch
 	DevBuf cmds, meta, cmd_open, counts, pt_local, cmd_box, rings, cmd_ring, rects_hdr, descs, tiles, flag;
@@ -109,6 +121,7 @@ struct FrontEnd {
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
 	uint32_t last_spans = 0;          // work-list length of the previous batch (grid guess of the one-submission form)
+	FePending pend;
 	uint32_t n_glyphs = 0, n_cmds = 0, n_segs = 0;
 	uint64_t out_bytes = 0;
 	vgsdf_dbatch batch; // borrowed view over the buffers above
@@ -739,69 +752,141 @@ int vgsdf_render_batch(vgsdf_ctx *ctx, const vgsdf_batch *in, uint8_t *out_bitma
 		}                                                                                       \
 	} while (0)
 
-// prepare, and — with a destination (`spec_out`, `spec_cap` bytes) — the raster enqueued right behind the front-end,
-// before the host has seen the plan: its grid and every capacity are guesses the plan kernel checks on the device
-// (PlanHeader::ok).  When they hold, the bitmaps are in `spec_out` after the ONE synchronisation of the call
-// (written there by the kernel itself if the buffer is page-locked); when not, the usual second launches run.
-// *rendered: the bitmaps are in spec_out.
-static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments,
-                      uint8_t *spec_out, size_t spec_cap, int *rendered)
+// ---- the front-end as two halves: submit (everything enqueued, nothing waited for) and wait (the one
+// synchronisation, the read-back, second launches if a guess was too small).  With a destination (`spec_out`,
+// `spec_cap` bytes) the raster is enqueued right behind the front-end kernels, before the host has seen the plan: its
+// grid and every capacity are guesses the plan kernel checks on the device (PlanHeader::ok).  When they hold, the
+// bitmaps are in `spec_out` after the wait (written there by the kernel itself if the buffer is page-locked).
+namespace {
+struct FeDev { // device views of a submitted batch
+	const vgsdf::OutlineCmd *cmds;
+	const double *scale, *shift;
+	const uint32_t *cmd_off;
+	vgsdf::OutlineRect *rects;
+	vgsdf::PlanHeader *hdr;
+	vgsdf::GlyphDesc *descs;
+};
+FeDev fe_dev(FrontEnd &fe)
 {
-	static const bool trace = std::getenv("VGSDF_TRACE") != nullptr;
-	if (rendered)
-		*rendered = 0;
+	const FePending &p = fe.pend;
+	const size_t n = p.n;
+	FeDev d;
+	d.cmds = (const vgsdf::OutlineCmd *)fe.cmds.p;
+	d.scale = (const double *)fe.meta.p;
+	d.shift = (const double *)((const uint8_t *)fe.meta.p + 8 * n);
+	d.cmd_off = (const uint32_t *)((const uint8_t *)fe.meta.p + 16 * n);
+	d.rects = (vgsdf::OutlineRect *)fe.rects_hdr.p;
+	d.hdr = (vgsdf::PlanHeader *)((uint8_t *)fe.rects_hdr.p + p.hdr_off);
+	d.descs = (vgsdf::GlyphDesc *)fe.descs.p;
+	return d;
+}
+int fe_launch_plan(vgsdf_ctx *ctx, FrontEnd &fe, uint32_t spans_launched)
+{
+	const FePending &p = fe.pend;
+	const FeDev d = fe_dev(fe);
+	return vgsdf_outline_plan(d.rects, p.n, p.span ? 1 : 0, (uint32_t)vgsdf_filtered_delta_cap(), p.span_max, p.span_budget,
+	                          (uint32_t)std::min<size_t>(fe.tile_cap, 0x7FFFFFFFu), d.descs, (uint2 *)fe.tiles.p, d.hdr,
+	                          (const uint32_t *)fe.flag.p, (unsigned long long)fe.seg_cap, (unsigned long long)p.spec_cap,
+	                          spans_launched, ctx->stream);
+}
+int fe_launch_emit(vgsdf_ctx *ctx, FrontEnd &fe)
+{
+	const FePending &p = fe.pend;
+	const FeDev d = fe_dev(fe);
+	int e = vgsdf_outline_emit_segments(d.cmds, p.n_cmds, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, (const uint32_t *)fe.pt_local.p,
+	                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d.descs, d.hdr,
+	                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, ctx->stream);
+	if (e == 0 && p.span)
+		e = vgsdf_launch_chunk_boxes(d.descs, p.n, (const double *)fe.seg.p, (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2,
+		                             (const double *)fe.seg.p + 3, 4, fe.boxes.p, d.hdr, (unsigned long long)fe.seg_cap, ctx->stream);
+	return e;
+}
+hipError_t fe_ensure_tiles(FrontEnd &fe, size_t want)
+{
+	if (want <= fe.tile_cap)
+		return hipSuccess;
+	hipError_t e = fe.tiles.ensure(sizeof(uint2) * want);
+	if (e == hipSuccess)
+		fe.tile_cap = fe.tiles.cap / sizeof(uint2);
+	return e;
+}
+hipError_t fe_ensure_segs(FrontEnd &fe, size_t want, uint32_t n_glyphs)
+{
+	if (want > fe.seg_cap) {
+		if (hipError_t e = fe.seg.ensure(32 * want + 32); e != hipSuccess)
+			return e;
+		fe.seg_cap = fe.seg.cap / 32 - 1;
+	}
+	return fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.seg_cap, n_glyphs) + 16);
+}
+} // namespace
+
+static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out, size_t spec_cap)
+{
 	const double tr0 = fe_now();
-	double tr1 = 0, tr2 = 0, tr3 = 0;
 	if (!ctx)
 		return VGSDF_E_ARG;
-	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x || !rects_out))) {
-		ctx->err = "vgsdf_outlines_prepare: NULL argument";
+	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x))) {
+		ctx->err = "vgsdf_outlines: NULL argument";
 		return VGSDF_E_ARG;
 	}
 	static_assert(sizeof(vgsdf_outline_cmd) == sizeof(vgsdf::OutlineCmd), "ABI struct mirrors the kernel struct");
 	static_assert(sizeof(vgsdf_rect) == sizeof(vgsdf::OutlineRect), "ABI struct mirrors the kernel struct");
 	const uint32_t n = in->n_glyphs;
 	if (n && in->cmd_off[0] != 0) {
-		ctx->err = "vgsdf_outlines_prepare: cmd_off[0] must be 0";
+		ctx->err = "vgsdf_outlines: cmd_off[0] must be 0";
 		return VGSDF_E_ARG;
 	}
 	for (uint32_t g = 0; g < n; g++)
 		if (in->cmd_off[g + 1] < in->cmd_off[g]) {
-			ctx->err = "vgsdf_outlines_prepare: cmd_off not monotone";
+			ctx->err = "vgsdf_outlines: cmd_off not monotone";
 			return VGSDF_E_ARG;
 		}
 	const uint32_t n_cmds = n ? in->cmd_off[n] : 0;
 	if (n_cmds && !in->cmds) {
-		ctx->err = "vgsdf_outlines_prepare: NULL command array";
+		ctx->err = "vgsdf_outlines: NULL command array";
 		return VGSDF_E_ARG;
 	}
-	// (the command kinds are checked further down, while the GPU already works on the upload: the
-	// kernels treat an unknown kind as a no-op, so nothing unsafe runs before the check)
+	// (the command kinds are checked on the device: the kernels treat an unknown kind as a no-op and the context
+	// pass raises the batch's error flag, so nothing unsafe runs and the host need not walk the commands)
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->fe)
 		ctx->fe = new (std::nothrow) FrontEnd();
 	if (!ctx->fe) {
-		ctx->err = "vgsdf_outlines_prepare: out of host memory";
+		ctx->err = "vgsdf_outlines: out of host memory";
 		return VGSDF_E_OOM;
 	}
 	FrontEnd &fe = *ctx->fe;
+	if (fe.pend.active) {
+		ctx->err = "vgsdf_outlines_submit: the previous submission of this context has not been waited for";
+		return VGSDF_E_ARG;
+	}
 	fe.prepared = false;
 	fe.n_glyphs = n;
 	fe.n_cmds = n_cmds;
 	fe.n_segs = 0;
 	fe.out_bytes = 0;
-	if (out_bytes)
-		*out_bytes = 0;
-	if (n_segments)
-		*n_segments = 0;
+	FePending &p = fe.pend;
+	p = FePending{};
+	p.n = n;
+	p.n_cmds = n_cmds;
+	p.spec_out = spec_out;
+	p.spec_cap = spec_out ? spec_cap : 0;
+	p.t0 = tr0;
 	if (n == 0) {
-		fe.prepared = true;
 		fe.batch.stats = vgsdf_stats{};
+		p.active = true;
+		p.t1 = fe_now();
 		return VGSDF_OK;
 	}
-	tr1 = fe_now();
+	p.t1 = fe_now();
 	hipStream_t st = ctx->stream;
-	const bool span = ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 69);
+	p.span = ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant <= 69);
+	// span policy of the work list (same switches as build_descs_and_tiles)
+	const char *sm = std::getenv("VGSDF_SPAN_MAX");
+	p.span_max = sm ? (uint32_t)std::min(4, std::max(1, std::atoi(sm))) : 4u;
+	const char *sb = std::getenv("VGSDF_SPAN_BUDGET");
+	p.span_budget = sb ? (uint32_t)std::max(1, std::atoi(sb)) : 16u;
 	FE_TRY(fe.cmds.ensure(sizeof(vgsdf::OutlineCmd) * (size_t)(n_cmds + 1)));
 	// per-glyph inputs (scale, shift, command offsets) travel as ONE block through pinned staging
 	const size_t meta_scale = 0, meta_shift = 8 * (size_t)n, meta_off = 16 * (size_t)n, meta_bytes = meta_off + 4 * (size_t)(n + 1);
@@ -813,34 +898,17 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 	FE_TRY(fe.cmd_box.ensure(32 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.rings.ensure(sizeof(vgsdf::RingRec) * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.cmd_ring.ensure(4 * (size_t)(n_cmds + 1)));
-	const size_t hdr_off = align_up(sizeof(vgsdf::OutlineRect) * (size_t)n, 16); // rects and totals: one block, one read-back
-	const size_t rh_bytes = hdr_off + sizeof(vgsdf::PlanHeader);
-	FE_TRY(fe.rects_hdr.ensure(rh_bytes));
-	FE_TRY(fe.h_rects.ensure(rh_bytes));
+	p.hdr_off = align_up(sizeof(vgsdf::OutlineRect) * (size_t)n, 16); // rects and totals: one block, one read-back
+	p.rh_bytes = p.hdr_off + sizeof(vgsdf::PlanHeader);
+	FE_TRY(fe.rects_hdr.ensure(p.rh_bytes));
+	FE_TRY(fe.h_rects.ensure(p.rh_bytes));
 	FE_TRY(fe.descs.ensure(sizeof(vgsdf::GlyphDesc) * (size_t)n + 16));
 	FE_TRY(fe.flag.ensure(16));
 	// capacities of what only the device knows the size of: the work list and the segment arrays.  Guessed from
 	// the input (and kept from earlier batches); the plan / emit kernels write nothing past them and the totals
 	// that come back with the rects say whether a second launch is needed.
-	auto ensure_tiles = [&](size_t want) -> hipError_t {
-		if (want <= fe.tile_cap)
-			return hipSuccess;
-		hipError_t e = fe.tiles.ensure(sizeof(uint2) * want);
-		if (e == hipSuccess)
-			fe.tile_cap = fe.tiles.cap / sizeof(uint2);
-		return e;
-	};
-	auto ensure_segs = [&](size_t want) -> hipError_t {
-		if (want <= fe.seg_cap)
-			return hipSuccess;
-		if (hipError_t e = fe.seg.ensure(32 * want + 32); e != hipSuccess)
-			return e;
-		fe.seg_cap = fe.seg.cap / 32 - 1;
-		return fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.seg_cap, n) + 16);
-	};
-	FE_TRY(ensure_tiles(2 * (size_t)n + 1024));
-	FE_TRY(ensure_segs(12 * (size_t)n_cmds + 4096));
-	FE_TRY(fe.boxes.ensure(vgsdf_chunk_box_bytes(fe.seg_cap, n) + 16));
+	FE_TRY(fe_ensure_tiles(fe, 2 * (size_t)n + 1024));
+	FE_TRY(fe_ensure_segs(fe, 12 * (size_t)n_cmds + 4096, n));
 
 	if (n_cmds)
 		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
@@ -852,77 +920,79 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
 	}
 	FE_TRY(hipMemsetAsync(fe.flag.p, 0, 16, st));
-	const double *d_scale = (const double *)((const uint8_t *)fe.meta.p + meta_scale);
-	const double *d_shift = (const double *)((const uint8_t *)fe.meta.p + meta_shift);
-	const uint32_t *d_cmd_off = (const uint32_t *)((const uint8_t *)fe.meta.p + meta_off);
-	auto *d_cmds = (const vgsdf::OutlineCmd *)fe.cmds.p;
-	auto *d_rects = (vgsdf::OutlineRect *)fe.rects_hdr.p;
-	auto *d_hdr = (vgsdf::PlanHeader *)((uint8_t *)fe.rects_hdr.p + hdr_off);
-	auto *d_descs = (vgsdf::GlyphDesc *)fe.descs.p;
+	const FeDev d = fe_dev(fe);
 
-	// span policy of the work list (same switches as build_descs_and_tiles)
-	const char *sm = std::getenv("VGSDF_SPAN_MAX");
-	const uint32_t span_max = sm ? (uint32_t)std::min(4, std::max(1, std::atoi(sm))) : 4u;
-	const char *sb = std::getenv("VGSDF_SPAN_BUDGET");
-	const uint32_t span_budget = sb ? (uint32_t)std::max(1, std::atoi(sb)) : 16u;
-	// the raster launch enqueued behind the front-end (one-submission form): default kernel only, destination the
-	// caller's page-locked buffer itself or, for pageable memory, the context's device buffer
-	const bool spec = spec_out != nullptr && spec_cap != 0 && ctx->variant == 0;
-	uint8_t *d_spec = nullptr;
-	uint32_t launch_spans = 0;
-	if (spec) {
+	// the raster launch enqueued behind the front-end: default kernel only, destination the caller's page-locked
+	// buffer itself or, for pageable memory, the context's device buffer
+	p.spec = spec_out != nullptr && spec_cap != 0 && ctx->variant == 0;
+	if (p.spec) {
 		if (is_pinned(spec_out, spec_cap)) {
-			d_spec = spec_out;
+			p.d_spec = spec_out;
 		} else {
 			FE_TRY(fe.out.ensure(spec_cap + 16));
-			d_spec = (uint8_t *)fe.out.p;
+			p.d_spec = (uint8_t *)fe.out.p;
 		}
 		const size_t guess = fe.last_spans ? (size_t)fe.last_spans + fe.last_spans / 2 + 256 : fe.tile_cap;
-		launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
+		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
-	auto launch_plan = [&](uint32_t spans_launched) {
-		return vgsdf_outline_plan(d_rects, n, span ? 1 : 0, (uint32_t)vgsdf_filtered_delta_cap(), span_max, span_budget,
-		                          (uint32_t)std::min<size_t>(fe.tile_cap, 0x7FFFFFFFu), d_descs, (uint2 *)fe.tiles.p, d_hdr,
-		                          (const uint32_t *)fe.flag.p, (unsigned long long)fe.seg_cap, (unsigned long long)spec_cap,
-		                          spans_launched, st);
-	};
-	auto launch_emit = [&]() -> int {
-		int e = vgsdf_outline_emit_segments(d_cmds, n_cmds, (const uint8_t *)fe.cmd_open.p, d_scale, d_shift, (const uint32_t *)fe.pt_local.p,
-		                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d_descs, d_hdr,
-		                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, st);
-		if (e == 0 && span)
-			e = vgsdf_launch_chunk_boxes(d_descs, n, (const double *)fe.seg.p, (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2,
-			                             (const double *)fe.seg.p + 3, 4, fe.boxes.p, d_hdr, (unsigned long long)fe.seg_cap, st);
-		return e;
-	};
-	FE_KERNEL(vgsdf_outline_context(d_cmds, d_cmd_off, d_scale, n, (uint8_t *)fe.cmd_open.p, st));
-	FE_KERNEL(vgsdf_outline_count(d_cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, d_cmd_off, n, d_scale, d_shift,
+	FE_KERNEL(vgsdf_outline_context(d.cmds, d.cmd_off, d.scale, n, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
+	FE_KERNEL(vgsdf_outline_count(d.cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, d.cmd_off, n, d.scale, d.shift,
 	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, st));
-	FE_KERNEL(vgsdf_outline_rings(d_cmds, d_cmd_off, (const uint8_t *)fe.cmd_open.p, d_scale, d_shift, n,
+	FE_KERNEL(vgsdf_outline_rings(d.cmds, d.cmd_off, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, n,
 	                              (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_local.p,
-	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d_rects,
+	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d.rects,
 	                              (uint32_t *)fe.flag.p, st));
-	FE_KERNEL(launch_plan(launch_spans));
-	FE_KERNEL(launch_emit());
-	if (spec)
-		FE_KERNEL(vgsdf_launch_span_planned(d_descs, (const uint2 *)fe.tiles.p, launch_spans, (const double *)fe.seg.p,
+	FE_KERNEL(fe_launch_plan(ctx, fe, p.launch_spans));
+	FE_KERNEL(fe_launch_emit(ctx, fe));
+	if (p.spec)
+		FE_KERNEL(vgsdf_launch_span_planned(d.descs, (const uint2 *)fe.tiles.p, p.launch_spans, (const double *)fe.seg.p,
 		                                    (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2, (const double *)fe.seg.p + 3, 4,
-		                                    d_spec, fe.boxes.p, d_hdr, st));
-	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, rh_bytes, hipMemcpyDeviceToHost, st));
-	// (the command kinds are checked here, while the GPU works: the kernels treat an unknown kind as a no-op,
-	// so nothing unsafe runs before the check)
-	bool kinds_ok = true;
-	for (uint32_t c = 0; c < n_cmds; c++)
-		kinds_ok &= in->cmds[c].kind <= 4u;
+		                                    p.d_spec, fe.boxes.p, d.hdr, st));
+	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, p.rh_bytes, hipMemcpyDeviceToHost, st));
+	p.active = true;
+	return VGSDF_OK;
+}
+
+static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered)
+{
+	static const bool trace = std::getenv("VGSDF_TRACE") != nullptr;
+	if (rendered)
+		*rendered = 0;
+	if (out_bytes)
+		*out_bytes = 0;
+	if (n_segments)
+		*n_segments = 0;
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!ctx->fe || !ctx->fe->pend.active) {
+		ctx->err = "vgsdf_outlines_wait: nothing was submitted";
+		return VGSDF_E_ARG;
+	}
+	FrontEnd &fe = *ctx->fe;
+	FePending &p = fe.pend;
+	const uint32_t n = p.n;
+	if (n && !rects_out) {
+		ctx->err = "vgsdf_outlines: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	p.active = false;
+	if (n == 0) {
+		fe.prepared = true;
+		if (rendered && p.spec_out)
+			*rendered = 1;
+		return VGSDF_OK;
+	}
+	(void)hipSetDevice(ctx->device);
+	hipStream_t st = ctx->stream;
 	FE_TRY(hipStreamSynchronize(st)); // the one read-back of the front-end
-	if (!kinds_ok) {
+	const double tr2 = fe_now();
+	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
+	vgsdf::PlanHeader hdr;
+	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + p.hdr_off, sizeof hdr);
+	if (hdr.error & 2u) {
 		ctx->err = "vgsdf_outlines_prepare: unknown command kind";
 		return VGSDF_E_ARG;
 	}
-	tr2 = fe_now();
-	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
-	vgsdf::PlanHeader hdr;
-	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + hdr_off, sizeof hdr);
 	if (hdr.error) {
 		ctx->err = "vgsdf_outlines_prepare: a glyph flattens to more than 2^28 points, the batch to more than 2^32 - 1 segments, or a "
 		           "bitmap exceeds 2^32 pixels (non-finite or absurd control points?)";
@@ -935,14 +1005,14 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 	// second launches when a capacity guess was too small (first batches of a context, unusual fonts)
 	const bool replan = hdr.n_spans > fe.tile_cap, reemit = hdr.n_segments > fe.seg_cap;
 	if (replan) {
-		FE_TRY(ensure_tiles((size_t)hdr.n_spans + hdr.n_spans / 4 + 1024));
-		FE_KERNEL(launch_plan(0));
+		FE_TRY(fe_ensure_tiles(fe, (size_t)hdr.n_spans + hdr.n_spans / 4 + 1024));
+		FE_KERNEL(fe_launch_plan(ctx, fe, 0));
 	}
 	if (reemit) {
-		FE_TRY(ensure_segs((size_t)hdr.n_segments + hdr.n_segments / 4 + 4096));
-		FE_KERNEL(launch_emit());
+		FE_TRY(fe_ensure_segs(fe, (size_t)hdr.n_segments + hdr.n_segments / 4 + 4096, n));
+		FE_KERNEL(fe_launch_emit(ctx, fe));
 	}
-	tr3 = fe_now();
+	const double tr3 = fe_now();
 
 	uint64_t n_pairs = 0;
 	for (uint32_t g = 0; g < n; g++) {
@@ -950,6 +1020,7 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 		if (r.has_raster)
 			n_pairs += (uint64_t)r.w * r.h * r.n_segments;
 	}
+	const FeDev d = fe_dev(fe);
 	fe.n_segs = (uint32_t)hdr.n_segments;
 	fe.out_bytes = hdr.out_bytes;
 	vgsdf_dbatch &b = fe.batch;
@@ -961,13 +1032,13 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 	b.stats.alg_bytes = 32 * (uint64_t)fe.n_segs + 32 * (uint64_t)n + fe.out_bytes;
 	b.out_bytes = (size_t)fe.out_bytes;
 	b.n_main = hdr.n_main;
-	b.span_list = span;
+	b.span_list = p.span;
 	b.tile_order = 1; // the device-built list is dispatched in list order
 	fe.last_spans = hdr.n_spans;
-	const bool done = spec && hdr.ok != 0; // the raster behind the plan ran over the whole list
-	if (!(done && d_spec == spec_out))
-		FE_TRY(fe.out.ensure(std::max((size_t)fe.out_bytes, done ? spec_cap : (size_t)0) + 16));
-	b.d_glyphs = d_descs;
+	const bool done = p.spec && hdr.ok != 0; // the raster behind the plan ran over the whole list
+	if (!(done && p.d_spec == p.spec_out))
+		FE_TRY(fe.out.ensure(std::max((size_t)fe.out_bytes, done ? p.spec_cap : (size_t)0) + 16));
+	b.d_glyphs = d.descs;
 	b.d_tiles = (uint2 *)fe.tiles.p;
 	b.d_sx = (double *)fe.seg.p;
 	b.d_sy = (double *)fe.seg.p + 1;
@@ -975,35 +1046,35 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 	b.d_ey = (double *)fe.seg.p + 3;
 	b.seg_stride = 4;
 	b.d_out = (uint8_t *)fe.out.p;
-	b.d_boxes = span ? fe.boxes.p : nullptr;
+	b.d_boxes = p.span ? fe.boxes.p : nullptr;
 	fe.prepared = true;
 	if (out_bytes)
 		*out_bytes = fe.out_bytes;
 	if (n_segments)
 		*n_segments = fe.n_segs;
-	if (spec_out && fe.out_bytes <= spec_cap) {
+	if (p.spec_out && fe.out_bytes <= p.spec_cap) {
 		int rc = VGSDF_OK;
 		if (done) {
-			if (d_spec != spec_out && fe.out_bytes) { // pageable destination: the raster wrote the device buffer
-				FE_TRY(hipMemcpyAsync(spec_out, d_spec, (size_t)fe.out_bytes, hipMemcpyDeviceToHost, st));
+			if (p.d_spec != p.spec_out && fe.out_bytes) { // pageable destination: the raster wrote the device buffer
+				FE_TRY(hipMemcpyAsync(p.spec_out, p.d_spec, (size_t)fe.out_bytes, hipMemcpyDeviceToHost, st));
 				FE_TRY(hipStreamSynchronize(st));
 			}
 		} else if (fe.out_bytes) { // a guess was too small (first batch of a context, a batch unlike the last one)
 			rc = vgsdf_batch_launch(ctx, &fe.batch);
 			if (rc == VGSDF_OK)
-				rc = vgsdf_batch_download(ctx, &fe.batch, spec_out);
+				rc = vgsdf_batch_download(ctx, &fe.batch, p.spec_out);
 		}
 		if (rc != VGSDF_OK)
 			return rc;
 		if (rendered)
 			*rendered = 1;
 	}
-	if (trace && spec_out)
+	if (trace && p.spec_out)
 		std::fprintf(stderr, "[vgsdf] one submission%s, %s destination\n", done ? "" : " (guess too small: second launches)",
-		             d_spec == spec_out ? "page-locked" : "pageable");
+		             p.d_spec == p.spec_out ? "page-locked" : "pageable");
 	if (trace)
-		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, upload + measure + plan + emit + read-back %.3f ms, second launches%s%s %.3f ms, host %.3f ms\n",
-		             (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, replan ? " (plan)" : "", reemit ? " (emit)" : "", (tr3 - tr2) * 1e3,
+		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, submit ... read-back %.3f ms, second launches%s%s %.3f ms, host %.3f ms\n",
+		             (p.t1 - p.t0) * 1e3, (tr2 - p.t1) * 1e3, replan ? " (plan)" : "", reemit ? " (emit)" : "", (tr3 - tr2) * 1e3,
 		             (fe_now() - tr3) * 1e3);
 	return VGSDF_OK;
 }
@@ -1011,17 +1082,33 @@ static int fe_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rect
 int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
                            uint64_t *n_segments)
 {
-	return fe_prepare(ctx, in, rects_out, out_bytes, n_segments, nullptr, 0, nullptr);
+	if (ctx && in && in->n_glyphs && !rects_out) {
+		ctx->err = "vgsdf_outlines_prepare: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	const int rc = fe_submit(ctx, in, nullptr, 0);
+	return rc != VGSDF_OK ? rc : fe_wait(ctx, rects_out, out_bytes, n_segments, nullptr);
+}
+
+int vgsdf_outlines_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *out_bitmaps, size_t out_capacity)
+{
+	return fe_submit(ctx, in, out_bitmaps, out_bitmaps ? out_capacity : 0);
+}
+
+int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered)
+{
+	return fe_wait(ctx, rects_out, out_bytes, n_segments, rendered);
 }
 
 int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint8_t *out_bitmaps,
                                size_t out_capacity, uint64_t *out_bytes, uint64_t *n_segments, int *rendered)
 {
-	if (ctx && !rendered) {
+	if (ctx && (!rendered || (in && in->n_glyphs && !rects_out))) {
 		ctx->err = "vgsdf_outlines_render_into: NULL argument";
 		return VGSDF_E_ARG;
 	}
-	return fe_prepare(ctx, in, rects_out, out_bytes, n_segments, out_bitmaps, out_bitmaps ? out_capacity : 0, rendered);
+	const int rc = fe_submit(ctx, in, out_bitmaps, out_bitmaps ? out_capacity : 0);
+	return rc != VGSDF_OK ? rc : fe_wait(ctx, rects_out, out_bytes, n_segments, rendered);
 }
 
 int vgsdf_outlines_render(vgsdf_ctx *ctx, uint8_t *out_bitmaps)

@@ -41,7 +41,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
-    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_segments",
+    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
 ]
 
 _lib = None
@@ -81,6 +81,8 @@ def load_library():
         L.vgsdf_outlines_prepare.argtypes = [vp, C.POINTER(_COutlines), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.vgsdf_outlines_render.argtypes = [vp, vp]
         L.vgsdf_outlines_render_into.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+        L.vgsdf_outlines_submit.argtypes = [vp, vp, vp, C.c_size_t]
+        L.vgsdf_outlines_wait.argtypes = [vp, vp, vp, vp, vp]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
