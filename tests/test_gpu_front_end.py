@@ -102,6 +102,30 @@ def test_one_submission_form_equals_prepare_plus_render(vg, fira_oracle):
     ctx2.close()
 
 
+def test_two_submissions_in_flight_on_two_contexts(vg, fira_oracle):
+    """vgsdf_outlines_submit / _wait: two contexts each hold a batch in flight (what FontManager does with its two
+    lanes); results equal prepare + render, a second submit before the wait is refused."""
+    ref = vg.SdfContext(0)
+    a, b = vg.SdfContext(0), vg.SdfContext(0)
+    batches = [record(vg, fira_oracle, range(lo, hi)) for lo, hi in [(0x20, 0x200), (0x200, 0x500), (0x30, 0x40), (0x20, 0x1000)]]
+    want = []
+    for cmd_off, cmds, scale, shift, _ in batches:
+        rects, ob, ns = ref.outlines_prepare(cmd_off, cmds, scale, shift)
+        want.append((rects.tobytes(), ref.outlines_render().tobytes(), ob, ns))
+    for rnd in range(2):  # second round: the contexts have their guesses from the first
+        for k in range(0, len(batches), 2):
+            a.outlines_submit(*batches[k][:4], want[k][2] + 64)
+            b.outlines_submit(*batches[k + 1][:4], want[k + 1][2] + 64)
+            with pytest.raises(vg.VgsdfError):
+                a.outlines_submit(*batches[k][:4], 1 << 20)   # one batch in flight per context
+            for c, j in ((a, k), (b, k + 1)):
+                rects, out, ob, ns = c.outlines_wait()
+                assert rects.tobytes() == want[j][0] and (ob, ns) == want[j][2:], (rnd, j)
+                assert out is not None and out.tobytes() == want[j][1], (rnd, j)
+    for c in (ref, a, b):
+        c.close()
+
+
 def test_arbitrary_command_streams(oracle, vg, ctx):
     # streams ttf-parser never emits: curve_to, quad_to on an empty ring, line_to starting a
     # ring, missing close, degenerate rings, repeated closes; rings via the oracle's RingBuilder

@@ -258,6 +258,40 @@ class SdfContext:
                 L.vgsdf_host_free(host)
         return rects, out, int(ob.value), int(ns.value)
 
+    def outlines_submit(self, cmd_off, cmds, scale, shift_x, capacity: int):
+        """first half of the one-submission form: everything is enqueued, nothing waited for (one per context)"""
+        L = load_library()
+        keep = {
+            "cmd_off": np.ascontiguousarray(cmd_off, dtype=np.uint32), "cmds": np.ascontiguousarray(cmds, dtype=OUTLINE_CMD_DTYPE),
+            "scale": np.ascontiguousarray(scale, dtype=np.float64), "shift": np.ascontiguousarray(shift_x, dtype=np.float64),
+        }
+        n = len(keep["scale"])
+        host = L.vgsdf_host_alloc(max(capacity, 1))
+        if not host:
+            raise MemoryError("vgsdf_host_alloc")
+        co = _COutlines(n, keep["cmd_off"].ctypes.data, keep["cmds"].ctypes.data, keep["scale"].ctypes.data, keep["shift"].ctypes.data)
+        rc = L.vgsdf_outlines_submit(self._h, C.byref(co), host, capacity)
+        if rc != 0:
+            L.vgsdf_host_free(host)
+            self._check(rc)
+        self._inflight = (keep, host, capacity, n)
+
+    def outlines_wait(self):
+        """second half -> (rects, bitmaps | None, out_bytes, n_segments)"""
+        L = load_library()
+        keep, host, capacity, n = self._inflight
+        self._inflight = None
+        try:
+            rects = np.zeros(n, dtype=RECT_DTYPE)
+            ob, ns, done = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+            self._check(L.vgsdf_outlines_wait(self._h, rects.ctypes.data, C.byref(ob), C.byref(ns), C.byref(done)))
+            self._fe = (n, int(ob.value), int(ns.value))
+            buf = (C.c_uint8 * max(capacity, 1)).from_address(host)
+            out = np.frombuffer(buf, dtype=np.uint8, count=int(ob.value)).copy() if done.value else None
+        finally:
+            L.vgsdf_host_free(host)
+        return rects, out, int(ob.value), int(ns.value)
+
     def outlines_render(self) -> np.ndarray:
         """device front-end, step 2: bitmaps of the glyphs with a raster, packed in glyph order"""
         out = np.empty(self._fe[1], dtype=np.uint8)
