@@ -1,8 +1,14 @@
 // thread_pool.hpp — persistent fork-join worker pool of the host stage.  The reference
 // hands (font, block) tasks to rayon's global pool (src/font/manager.rs:117-121); here the
 // same tasks are tessellated / packed / encoded by these workers around one GPU submission.
+//
+// A font goes through three fork/joins (record, merge, encode) of ~0.1 ms each, so the hand-over matters as much
+// as the work: workers poll the generation counter for a short while after finishing (the next fork usually
+// follows within microseconds) before they sleep on the condition variable, and the caller polls the count of
+// busy workers before it sleeps (a futex wake-up of 15 sleeping threads costs 20-50 us per fork).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <exception>
 #include <functional>
@@ -25,7 +31,7 @@ public:
 		{
 			std::lock_guard<std::mutex> l(mu_);
 			stop_ = true;
-			gen_++;
+			gen_.fetch_add(1, std::memory_order_release);
 		}
 		cv_.notify_all();
 		for (auto &th : threads_)
@@ -46,19 +52,38 @@ public:
 			next_.store(0);
 			failed_.store(false);
 			error_.clear();
-			pending_ = n_ - 1;
-			gen_++;
+			pending_.store(n_ - 1, std::memory_order_relaxed);
+			gen_.fetch_add(1, std::memory_order_release);
 		}
-		cv_.notify_all();
+		if (sleepers_.load(std::memory_order_acquire) != 0)
+			cv_.notify_all();
 		work(0);
-		std::unique_lock<std::mutex> l(mu_);
-		done_cv_.wait(l, [this] { return pending_ == 0; });
+		if (!poll([this] { return pending_.load(std::memory_order_acquire) == 0; })) {
+			std::unique_lock<std::mutex> l(mu_);
+			done_cv_.wait(l, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+		}
 		fn_ = nullptr;
 		if (failed_.load())
 			throw std::runtime_error(error_);
 	}
 
 private:
+	// busy-wait for `ready` for at most ~100 us; true when it came
+	template <class Ready> static bool poll(Ready ready)
+	{
+		const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+		for (;;) {
+			for (int i = 0; i < 64; i++) {
+				if (ready())
+					return true;
+#if defined(__x86_64__) || defined(__i386__)
+				__builtin_ia32_pause();
+#endif
+			}
+			if (std::chrono::steady_clock::now() >= until)
+				return ready();
+		}
+	}
 	void work(unsigned id)
 	{
 		for (;;) {
@@ -78,17 +103,24 @@ private:
 	{
 		uint64_t seen = 0;
 		for (;;) {
-			{
+			if (!poll([&] { return gen_.load(std::memory_order_acquire) != seen; })) {
 				std::unique_lock<std::mutex> l(mu_);
-				cv_.wait(l, [&] { return gen_ != seen; });
-				seen = gen_;
+				sleepers_.fetch_add(1, std::memory_order_release);
+				cv_.wait(l, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+				sleepers_.fetch_sub(1, std::memory_order_release);
+			}
+			{
+				// (the fields of the fork are published under the mutex: take it once before reading them)
+				std::lock_guard<std::mutex> l(mu_);
+				seen = gen_.load(std::memory_order_acquire);
 				if (stop_)
 					return;
 			}
 			work(id);
-			std::lock_guard<std::mutex> l(mu_);
-			if (--pending_ == 0)
+			if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+				std::lock_guard<std::mutex> l(mu_); // (pairs with the caller's wait: no lost wake-up)
 				done_cv_.notify_one();
+			}
 		}
 	}
 
@@ -101,8 +133,8 @@ private:
 	std::atomic<size_t> next_{0};
 	std::atomic<bool> failed_{false};
 	std::string error_;
-	unsigned pending_ = 0;
-	uint64_t gen_ = 0;
+	std::atomic<unsigned> pending_{0}, sleepers_{0};
+	std::atomic<uint64_t> gen_{0};
 	bool stop_ = false;
 };
 
