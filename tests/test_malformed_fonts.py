@@ -94,8 +94,8 @@ def _retag(data: bytes, old: bytes, new: bytes) -> bytes:
 
 
 def test_cff_and_cmapless_fonts_are_refused(vg):
-    """A font whose outlines live in `CFF ` must not silently render as empty glyphs (the reference
-    renders CFF through ttf-parser's curve_to; this reader is glyf-only), and a font without a cmap
+    """A font whose outlines live in a table this reader cannot walk (here: a `CFF ` table that does not parse;
+    `CFF2` in tests/test_cff_outlines.py) must not silently render as empty glyphs, and a font without a cmap
     table fails as in the reference ("Font has no cmap table", src/font/metadata.rs:104-107)."""
     from conftest import FIRA
     data = Path(FIRA).read_bytes()

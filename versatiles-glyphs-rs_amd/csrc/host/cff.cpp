@@ -1,0 +1,702 @@
+// cff.cpp — see cff.hpp.
+#include "cff.hpp"
+
+#include <cmath>
+#include <limits>
+
+namespace vg {
+
+namespace {
+
+constexpr int kMaxOperands = 48; // ttf-parser: MAX_ARGUMENTS_STACK_LEN
+constexpr int kMaxDepth = 10;    // ttf-parser: STACK_LIMIT (nested subroutine calls)
+
+// DICT data (Technical Note #5176, section 4): operands followed by an operator
+struct DictReader {
+	explicit DictReader(Bytes dict) : d(dict) {}
+	Bytes d;
+	size_t pos = 0;
+	std::vector<double> operands;
+	// next operator (two-byte operators as 1200 + second byte), -1 at the end, -2 on malformed data
+	int next()
+	{
+		operands.clear();
+		while (pos < d.size()) {
+			const uint8_t b = d.u8(pos);
+			if (b <= 21) {
+				pos++;
+				if (b != 12)
+					return b;
+				if (pos >= d.size())
+					return -2;
+				return 1200 + d.u8(pos++);
+			}
+			if (b == 28) {
+				if (!d.has(pos, 3))
+					return -2;
+				operands.push_back((double)d.i16(pos + 1));
+				pos += 3;
+			} else if (b == 29) {
+				if (!d.has(pos, 5))
+					return -2;
+				operands.push_back((double)(int32_t)d.u32(pos + 1));
+				pos += 5;
+			} else if (b == 30) { // real number: nibbles up to 0xf; only skipped (no operator of interest takes one)
+				pos++;
+				bool done = false;
+				while (!done) {
+					if (pos >= d.size())
+						return -2;
+					const uint8_t v = d.u8(pos++);
+					done = (v >> 4) == 0xF || (v & 0xF) == 0xF;
+				}
+				operands.push_back(0.0);
+			} else if (b >= 32 && b <= 246) {
+				operands.push_back((double)((int)b - 139));
+				pos++;
+			} else if (b >= 247 && b <= 250) {
+				if (!d.has(pos, 2))
+					return -2;
+				operands.push_back((double)(((int)b - 247) * 256 + d.u8(pos + 1) + 108));
+				pos += 2;
+			} else if (b >= 251 && b <= 254) {
+				if (!d.has(pos, 2))
+					return -2;
+				operands.push_back((double)(-((int)b - 251) * 256 - d.u8(pos + 1) - 108));
+				pos += 2;
+			} else {
+				return -2; // 22-27, 31, 255: reserved
+			}
+			if (operands.size() > 513)
+				return -2;
+		}
+		return -1;
+	}
+};
+
+bool to_offset(double v, size_t &out)
+{
+	if (!(v >= 0.0 && v <= 4294967295.0))
+		return false;
+	out = (size_t)v;
+	return true;
+}
+
+} // namespace
+
+bool CffTable::parse_index(Bytes table, size_t at, Index &out, size_t &end)
+{
+	out = Index{};
+	if (!table.has(at, 2))
+		return false;
+	const uint32_t count = table.u16(at);
+	if (count == 0) {
+		end = at + 2;
+		return true;
+	}
+	if (!table.has(at, 3))
+		return false;
+	const uint8_t off_size = table.u8(at + 2);
+	if (off_size < 1 || off_size > 4)
+		return false;
+	const size_t offsets_at = at + 3, offsets_len = ((size_t)count + 1) * off_size;
+	if (!table.has(offsets_at, offsets_len))
+		return false;
+	auto off = [&](uint32_t i) {
+		uint32_t v = 0;
+		for (uint8_t k = 0; k < off_size; k++)
+			v = (v << 8) | table.u8(offsets_at + (size_t)i * off_size + k);
+		return v;
+	};
+	const uint32_t last = off(count);
+	if (last < 1)
+		return false;
+	const size_t data_at = offsets_at + offsets_len; // offsets are relative to the byte before the data
+	if (!table.has(data_at, (size_t)last - 1))
+		return false;
+	out.data = table;
+	out.count = count;
+	out.off_size = off_size;
+	out.offsets_at = offsets_at;
+	out.data_at = data_at;
+	end = data_at + last - 1;
+	return true;
+}
+
+std::optional<Bytes> CffTable::Index::get(uint32_t i) const
+{
+	if (i >= count)
+		return std::nullopt;
+	auto off = [&](uint32_t k) {
+		uint32_t v = 0;
+		for (uint8_t b = 0; b < off_size; b++)
+			v = (v << 8) | data.u8(offsets_at + (size_t)k * off_size + b);
+		return v;
+	};
+	const uint32_t a = off(i), b = off(i + 1);
+	if (a < 1 || b < a)
+		return std::nullopt;
+	if (!data.has(data_at + a - 1, b - a))
+		return std::nullopt;
+	return data.sub(data_at + a - 1, b - a);
+}
+
+bool CffTable::parse_private(Bytes table, size_t offset, size_t size, PrivateDict &out)
+{
+	out = PrivateDict{};
+	if (!table.has(offset, size))
+		return false;
+	DictReader r(table.sub(offset, size));
+	for (int op = r.next(); op != -1; op = r.next()) {
+		if (op == -2)
+			return false;
+		if (op == 19 && r.operands.size() == 1) { // Subrs: offset relative to the Private DICT
+			size_t rel;
+			if (!to_offset(r.operands[0], rel))
+				return false;
+			size_t end;
+			if (!parse_index(table, offset + rel, out.local_subrs, end))
+				return false;
+		}
+	}
+	return true;
+}
+
+std::optional<CffTable> CffTable::parse(Bytes table)
+{
+	if (!table.has(0, 4) || table.u8(0) != 1) // major version 1 (CFF2 is another table)
+		return std::nullopt;
+	CffTable t;
+	t.table_ = table;
+	size_t pos = table.u8(2); // hdrSize
+	Index names, top_dicts, strings;
+	if (!parse_index(table, pos, names, pos) || !parse_index(table, pos, top_dicts, pos) || !parse_index(table, pos, strings, pos) ||
+	    !parse_index(table, pos, t.global_subrs_, pos))
+		return std::nullopt;
+	const auto top = top_dicts.get(0);
+	if (!top)
+		return std::nullopt;
+	size_t charstrings_at = 0, private_size = 0, private_at = 0, fd_array_at = 0, fd_select_at = 0;
+	bool have_private = false;
+	DictReader r(*top);
+	for (int op = r.next(); op != -1; op = r.next()) {
+		if (op == -2)
+			return std::nullopt;
+		const auto &v = r.operands;
+		if (op == 17 && v.size() == 1) {
+			if (!to_offset(v[0], charstrings_at))
+				return std::nullopt;
+		} else if (op == 18 && v.size() == 2) {
+			if (!to_offset(v[0], private_size) || !to_offset(v[1], private_at))
+				return std::nullopt;
+			have_private = true;
+		} else if (op == 1206 && v.size() == 1) { // CharstringType
+			if (v[0] != 2.0)
+				return std::nullopt;
+		} else if (op == 1230) { // ROS: CID-keyed
+			t.cid_ = true;
+		} else if (op == 1236 && v.size() == 1) {
+			if (!to_offset(v[0], fd_array_at))
+				return std::nullopt;
+		} else if (op == 1237 && v.size() == 1) {
+			if (!to_offset(v[0], fd_select_at))
+				return std::nullopt;
+		}
+	}
+	size_t end;
+	if (charstrings_at == 0 || !parse_index(table, charstrings_at, t.charstrings_, end) || t.charstrings_.count == 0)
+		return std::nullopt;
+	if (t.cid_) {
+		Index fd_array;
+		if (fd_array_at == 0 || fd_select_at == 0 || !parse_index(table, fd_array_at, fd_array, end) || !table.has(fd_select_at, 1))
+			return std::nullopt;
+		t.fd_select_ = table.from(fd_select_at);
+		for (uint32_t i = 0; i < fd_array.count; i++) {
+			PrivateDict pd;
+			if (const auto fd = fd_array.get(i)) {
+				DictReader fr(*fd);
+				for (int op = fr.next(); op != -1 && op != -2; op = fr.next())
+					if (op == 18 && fr.operands.size() == 2) {
+						size_t sz, at;
+						if (to_offset(fr.operands[0], sz) && to_offset(fr.operands[1], at))
+							(void)parse_private(table, at, sz, pd);
+					}
+			}
+			t.fd_priv_.push_back(pd);
+		}
+	} else if (have_private) {
+		(void)parse_private(table, private_at, private_size, t.private_); // (a broken Private DICT only costs the local subroutines)
+	}
+	return t;
+}
+
+const CffTable::Index *CffTable::local_subrs_for(uint16_t gid) const
+{
+	if (!cid_)
+		return &private_.local_subrs;
+	// FDSelect (Technical Note #5176, section 19): format 0 = one byte per glyph, format 3 = ranges
+	uint32_t fd = 0xFFFFFFFFu;
+	const Bytes &s = fd_select_;
+	if (s.has(0, 1) && s.u8(0) == 0) {
+		if (s.has(1 + (size_t)gid, 1))
+			fd = s.u8(1 + (size_t)gid);
+	} else if (s.has(0, 3) && s.u8(0) == 3) {
+		const uint32_t n = s.u16(1);
+		for (uint32_t i = 0; i < n; i++) {
+			const size_t rec = 3 + (size_t)i * 3;
+			if (!s.has(rec, 5))
+				break;
+			const uint32_t first = s.u16(rec), next = s.u16(rec + 3);
+			if (gid >= first && gid < next) {
+				fd = s.u8(rec + 2);
+				break;
+			}
+		}
+	}
+	return fd < fd_priv_.size() ? &fd_priv_[fd].local_subrs : nullptr;
+}
+
+// One glyph's charstring program (Technical Note #5177).
+struct CharStringRun {
+	CharStringRun(const CffTable &table, OutlineBuilder &builder) : t(table), out(builder) {}
+	const CffTable &t;
+	OutlineBuilder &out;
+	const CffTable::Index *local = nullptr;
+	float stack[kMaxOperands];
+	int sp = 0;
+	float x = 0.0f, y = 0.0f;
+	bool has_move_to = false, first_move_to = true, have_width = false, has_endchar = false;
+	uint32_t stems = 0;
+	// bbox of everything handed to the builder (control points included), as ttf-parser's Builder keeps it
+	float bx0 = std::numeric_limits<float>::max(), by0 = std::numeric_limits<float>::max();
+	float bx1 = std::numeric_limits<float>::lowest(), by1 = std::numeric_limits<float>::lowest();
+
+	void extend(float px, float py)
+	{
+		bx0 = px < bx0 ? px : bx0;
+		by0 = py < by0 ? py : by0;
+		bx1 = px > bx1 ? px : bx1;
+		by1 = py > by1 ? py : by1;
+	}
+	void move_to(float px, float py)
+	{
+		extend(px, py);
+		out.move_to(px, py);
+	}
+	void line_to(float px, float py)
+	{
+		extend(px, py);
+		out.line_to(px, py);
+	}
+	void curve_to(float x1, float y1, float x2, float y2, float px, float py)
+	{
+		extend(x1, y1);
+		extend(x2, y2);
+		extend(px, py);
+		out.curve_to(x1, y1, x2, y2, px, py);
+	}
+	bool push(float v)
+	{
+		if (sp >= kMaxOperands)
+			return false;
+		stack[sp++] = v;
+		return true;
+	}
+	static uint32_t bias(uint32_t n) { return n < 1240 ? 107 : (n < 33900 ? 1131 : 32768); }
+
+	bool do_move(int skip, bool hx, bool hy)
+	{
+		const int want = (hx ? 1 : 0) + (hy ? 1 : 0);
+		if (sp != skip + want)
+			return false;
+		if (first_move_to)
+			first_move_to = false;
+		else
+			out.close();
+		has_move_to = true;
+		int i = skip;
+		if (hx)
+			x += stack[i++];
+		if (hy)
+			y += stack[i++];
+		move_to(x, y);
+		sp = 0;
+		return true;
+	}
+	bool do_alternating_lines(bool horizontal)
+	{
+		if (!has_move_to || sp == 0)
+			return false;
+		for (int i = 0; i < sp; i++) {
+			if (horizontal)
+				x += stack[i];
+			else
+				y += stack[i];
+			horizontal = !horizontal;
+			line_to(x, y);
+		}
+		sp = 0;
+		return true;
+	}
+	void curve_rel(int i)
+	{
+		const float x1 = x + stack[i], y1 = y + stack[i + 1];
+		const float x2 = x1 + stack[i + 2], y2 = y1 + stack[i + 3];
+		x = x2 + stack[i + 4];
+		y = y2 + stack[i + 5];
+		curve_to(x1, y1, x2, y2, x, y);
+	}
+	// hvcurveto / vhcurveto: curves that start horizontal and vertical in turn; the last may carry a fifth operand
+	bool do_hv_curves(bool horizontal)
+	{
+		if (!has_move_to || sp < 4)
+			return false;
+		int i = 0;
+		while (i < sp) {
+			const int left = sp - i;
+			if (left < 4)
+				return false;
+			const float last = left == 5 ? stack[i + 4] : 0.0f;
+			if (horizontal) {
+				const float x1 = x + stack[i], y1 = y;
+				const float x2 = x1 + stack[i + 1], y2 = y1 + stack[i + 2];
+				y = y2 + stack[i + 3];
+				x = x2 + last;
+				curve_to(x1, y1, x2, y2, x, y);
+			} else {
+				const float x1 = x, y1 = y + stack[i];
+				const float x2 = x1 + stack[i + 1], y2 = y1 + stack[i + 2];
+				x = x2 + stack[i + 3];
+				y = y2 + last;
+				curve_to(x1, y1, x2, y2, x, y);
+			}
+			i += left == 5 ? 5 : 4;
+			horizontal = !horizontal;
+		}
+		sp = 0;
+		return true;
+	}
+
+	// false: the glyph has no outline (ttf-parser: Err -> None)
+	bool run(Bytes cs, int depth)
+	{
+		size_t pos = 0;
+		while (pos < cs.size()) {
+			const uint8_t op = cs.u8(pos++);
+			if (op >= 32 || op == 28) { // operands
+				float v;
+				if (op == 28) {
+					if (!cs.has(pos, 2))
+						return false;
+					v = (float)cs.i16(pos);
+					pos += 2;
+				} else if (op <= 246) {
+					v = (float)((int)op - 139);
+				} else if (op <= 250) {
+					if (!cs.has(pos, 1))
+						return false;
+					v = (float)(((int)op - 247) * 256 + cs.u8(pos) + 108);
+					pos += 1;
+				} else if (op <= 254) {
+					if (!cs.has(pos, 1))
+						return false;
+					v = (float)(-((int)op - 251) * 256 - cs.u8(pos) - 108);
+					pos += 1;
+				} else { // 255: 16.16 fixed
+					if (!cs.has(pos, 4))
+						return false;
+					v = (float)(int32_t)cs.u32(pos) / 65536.0f;
+					pos += 4;
+				}
+				if (!push(v))
+					return false;
+				continue;
+			}
+			switch (op) {
+			case 1:  // hstem
+			case 3:  // vstem
+			case 18: // hstemhm
+			case 23: // vstemhm
+			{
+				int len = sp;
+				if ((len & 1) && !have_width) { // an odd count: the first operand is the width
+					have_width = true;
+					len--;
+				}
+				stems += (uint32_t)len >> 1;
+				sp = 0;
+				break;
+			}
+			case 19: // hintmask
+			case 20: // cntrmask
+			{
+				int len = sp;
+				sp = 0;
+				if (len & 1) {
+					len--;
+					have_width = true;
+				}
+				stems += (uint32_t)len >> 1; // an implied vstem
+				pos += (stems + 7) >> 3;
+				if (pos > cs.size())
+					return false;
+				break;
+			}
+			case 21: // rmoveto
+			{
+				int skip = 0;
+				if (sp == 3) {
+					skip = 1;
+					have_width = true;
+				}
+				if (!do_move(skip, true, true))
+					return false;
+				break;
+			}
+			case 22: // hmoveto
+			{
+				int skip = 0;
+				if (sp == 2) {
+					skip = 1;
+					have_width = true;
+				}
+				if (!do_move(skip, true, false))
+					return false;
+				break;
+			}
+			case 4: // vmoveto
+			{
+				int skip = 0;
+				if (sp == 2) {
+					skip = 1;
+					have_width = true;
+				}
+				if (!do_move(skip, false, true))
+					return false;
+				break;
+			}
+			case 5: // rlineto
+				if (!has_move_to || (sp & 1))
+					return false;
+				for (int i = 0; i < sp; i += 2) {
+					x += stack[i];
+					y += stack[i + 1];
+					line_to(x, y);
+				}
+				sp = 0;
+				break;
+			case 6: // hlineto
+				if (!do_alternating_lines(true))
+					return false;
+				break;
+			case 7: // vlineto
+				if (!do_alternating_lines(false))
+					return false;
+				break;
+			case 8: // rrcurveto
+				if (!has_move_to || sp % 6 != 0)
+					return false;
+				for (int i = 0; i < sp; i += 6)
+					curve_rel(i);
+				sp = 0;
+				break;
+			case 24: // rcurveline
+			{
+				if (!has_move_to || sp < 8 || (sp - 2) % 6 != 0)
+					return false;
+				int i = 0;
+				for (; i + 6 <= sp - 2; i += 6)
+					curve_rel(i);
+				x += stack[i];
+				y += stack[i + 1];
+				line_to(x, y);
+				sp = 0;
+				break;
+			}
+			case 25: // rlinecurve
+			{
+				if (!has_move_to || sp < 8 || ((sp - 6) & 1))
+					return false;
+				int i = 0;
+				for (; i + 2 <= sp - 6; i += 2) {
+					x += stack[i];
+					y += stack[i + 1];
+					line_to(x, y);
+				}
+				curve_rel(i);
+				sp = 0;
+				break;
+			}
+			case 26: // vvcurveto
+			{
+				if (!has_move_to)
+					return false;
+				int i = 0;
+				if (sp & 1) {
+					x += stack[0];
+					i = 1;
+				}
+				if ((sp - i) % 4 != 0)
+					return false;
+				for (; i < sp; i += 4) {
+					const float x1 = x, y1 = y + stack[i];
+					const float x2 = x1 + stack[i + 1], y2 = y1 + stack[i + 2];
+					x = x2;
+					y = y2 + stack[i + 3];
+					curve_to(x1, y1, x2, y2, x, y);
+				}
+				sp = 0;
+				break;
+			}
+			case 27: // hhcurveto
+			{
+				if (!has_move_to)
+					return false;
+				int i = 0;
+				if (sp & 1) {
+					y += stack[0];
+					i = 1;
+				}
+				if ((sp - i) % 4 != 0)
+					return false;
+				for (; i < sp; i += 4) {
+					const float x1 = x + stack[i], y1 = y;
+					const float x2 = x1 + stack[i + 1], y2 = y1 + stack[i + 2];
+					x = x2 + stack[i + 3];
+					y = y2;
+					curve_to(x1, y1, x2, y2, x, y);
+				}
+				sp = 0;
+				break;
+			}
+			case 30: // vhcurveto
+				if (!do_hv_curves(false))
+					return false;
+				break;
+			case 31: // hvcurveto
+				if (!do_hv_curves(true))
+					return false;
+				break;
+			case 10: // callsubr
+			case 29: // callgsubr
+			{
+				if (sp == 0 || depth == kMaxDepth)
+					return false;
+				const CffTable::Index *subrs = op == 29 ? &t.global_subrs_ : local;
+				if (!subrs)
+					return false;
+				const float fidx = stack[--sp];
+				const long idx = (long)fidx + (long)bias(subrs->count);
+				if ((float)(long)fidx != fidx || idx < 0 || idx >= (long)subrs->count)
+					return false;
+				const auto sub = subrs->get((uint32_t)idx);
+				if (!sub || !run(*sub, depth + 1))
+					return false;
+				if (has_endchar) {
+					if (pos != cs.size())
+						return false; // data after endchar
+					return true;
+				}
+				break;
+			}
+			case 11: // return
+				return true;
+			case 14: // endchar
+				if (sp == 4 || (!have_width && sp == 5))
+					return false; // seac form (accented character from two glyphs of the standard encoding): not handled
+				if (sp == 1 && !have_width)
+					have_width = true;
+				sp = 0;
+				if (!first_move_to) {
+					first_move_to = true;
+					out.close();
+				}
+				if (pos != cs.size())
+					return false; // data after endchar
+				has_endchar = true;
+				return true;
+			case 12: {
+				if (pos >= cs.size())
+					return false;
+				const uint8_t op2 = cs.u8(pos++);
+				if (!has_move_to)
+					return false;
+				if (op2 == 35) { // flex
+					if (sp != 13)
+						return false;
+					curve_rel(0);
+					curve_rel(6);
+				} else if (op2 == 34) { // hflex
+					if (sp != 7)
+						return false;
+					const float y0 = y;
+					float x1 = x + stack[0], y1 = y;
+					float x2 = x1 + stack[1], y2 = y1 + stack[2];
+					x = x2 + stack[3];
+					y = y2;
+					curve_to(x1, y1, x2, y2, x, y);
+					x1 = x + stack[4], y1 = y;
+					x2 = x1 + stack[5], y2 = y0;
+					x = x2 + stack[6];
+					y = y0;
+					curve_to(x1, y1, x2, y2, x, y);
+				} else if (op2 == 36) { // hflex1
+					if (sp != 9)
+						return false;
+					const float y0 = y;
+					float x1 = x + stack[0], y1 = y + stack[1];
+					float x2 = x1 + stack[2], y2 = y1 + stack[3];
+					x = x2 + stack[4];
+					y = y2;
+					curve_to(x1, y1, x2, y2, x, y);
+					x1 = x + stack[5], y1 = y;
+					x2 = x1 + stack[6], y2 = y1 + stack[7];
+					x = x2 + stack[8];
+					y = y0;
+					curve_to(x1, y1, x2, y2, x, y);
+				} else if (op2 == 37) { // flex1
+					if (sp != 11)
+						return false;
+					const float x0 = x, y0 = y;
+					curve_rel(0);
+					const float x1 = x + stack[6], y1 = y + stack[7];
+					const float x2 = x1 + stack[8], y2 = y1 + stack[9];
+					if (std::fabs(x2 - x0) > std::fabs(y2 - y0)) {
+						x = x2 + stack[10];
+						y = y0;
+					} else {
+						x = x0;
+						y = y2 + stack[10];
+					}
+					curve_to(x1, y1, x2, y2, x, y);
+				} else {
+					return false; // arithmetic, storage and conditional operators: unsupported (as in ttf-parser)
+				}
+				sp = 0;
+				break;
+			}
+			default:
+				return false; // 0, 2, 9, 13, 15, 16, 17: reserved
+			}
+		}
+		return true;
+	}
+};
+
+bool CffTable::outline(uint16_t gid, OutlineBuilder &builder) const
+{
+	const auto cs = charstrings_.get(gid);
+	if (!cs)
+		return false;
+	CharStringRun r(*this, builder);
+	r.local = local_subrs_for(gid);
+	if (!r.run(*cs, 0) || !r.has_endchar)
+		return false;
+	// ttf-parser: a glyph that produced no point has no outline (ZeroBBox); neither has one whose bbox leaves i16
+	if (r.bx0 == std::numeric_limits<float>::max())
+		return false;
+	auto fits = [](float v) { return v >= -32768.0f && v <= 32767.0f; };
+	return fits(r.bx0) && fits(r.by0) && fits(r.bx1) && fits(r.by1);
+}
+
+} // namespace vg

@@ -83,12 +83,12 @@ std::unique_ptr<FontFileEntry> FontFileEntry::create(std::vector<uint8_t> data, 
 			*err = "Font has no cmap table";
 		return nullptr;
 	}
-	// The reference renders CFF outlines through ttf-parser's curve_to; this reader emits `glyf` outlines
-	// only.  Refuse such a font loudly instead of writing PBFs whose glyphs are all empty.  (A font with
-	// neither glyf nor CFF outlines renders empty glyphs in the reference too: outline_glyph -> None.)
-	if (!e->face_.has_glyf_outlines() && e->face_.has_cff_outlines()) {
+	// The reference renders `glyf`, `CFF ` and `CFF2` outlines through ttf-parser; this reader walks the first two.
+	// Refuse a font whose outlines it cannot walk loudly instead of writing PBFs whose glyphs are all empty.  (A
+	// font with no outline table at all renders empty glyphs in the reference too: outline_glyph -> None.)
+	if (e->face_.has_unsupported_outlines()) {
 		if (err)
-			*err = "CFF / CFF2 outlines are not supported (glyf fonts only)";
+			*err = "CFF2 outlines (or an unreadable CFF table) are not supported: glyf and CFF version 1 fonts only";
 		return nullptr;
 	}
 	e->codepoints_ = e->face_.unicode_codepoints();

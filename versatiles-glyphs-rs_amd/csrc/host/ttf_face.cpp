@@ -5,6 +5,8 @@
 // -ffp-contract=off), as Rust does.
 #include "ttf_face.hpp"
 
+#include "cff.hpp"
+
 #include <algorithm>
 #include <cstring>
 
@@ -53,7 +55,14 @@ std::optional<Face> Face::parse(const uint8_t *data, size_t len)
 		f.loca_entries_ = std::min(want, f.loca_.size() / (f.loca_long_ ? 4u : 2u));
 	}
 	f.name_ = find_table(file, "name");
-	f.has_cff_ = !find_table(file, "CFF ").empty() || !find_table(file, "CFF2").empty();
+	if (const Bytes cff = find_table(file, "CFF "); !cff.empty()) {
+		if (auto t = CffTable::parse(cff))
+			f.cff_ = std::make_shared<const CffTable>(std::move(*t));
+		else
+			f.cff_unreadable_ = true;
+	}
+	if (!f.cff_ && !find_table(file, "CFF2").empty())
+		f.cff_unreadable_ = true;
 	const Bytes cmap = find_table(file, "cmap");
 	f.has_cmap_ = cmap.has(0, 4);
 	if (cmap.has(0, 4)) {
@@ -667,6 +676,8 @@ struct GlyfWalker {
 
 bool Face::outline_glyph(uint16_t gid, OutlineBuilder &builder) const
 {
+	if (!has_glyf_outlines() && cff_) // ttf-parser: glyf first, then cff
+		return cff_->outline(gid, builder);
 	const auto g = glyph_data(gid);
 	if (!g)
 		return false;

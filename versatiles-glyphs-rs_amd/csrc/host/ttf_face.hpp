@@ -6,17 +6,20 @@
 //   Face::outline_glyph      renderer.rs:110   (glyf outlines -> OutlineBuilder callbacks)
 //   Face::glyph_hor_advance  renderer.rs:115
 //   cmap subtable walk       src/font/metadata.rs:105-117 (code point coverage)
-// Static TrueType (`glyf`) fonts only; CFF / variable fonts are out of scope (none in the
-// reference's testdata) and are reported as "no outline".
+// Static fonts: TrueType (`glyf`) outlines and `CFF ` (version 1) charstrings (cff.hpp); CFF2 / variable
+// fonts are out of scope (none in the reference's testdata) and are refused at load time.
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <optional>
 #include <string>
 #include <utility>
 #include <vector>
 
 namespace vg {
+
+class CffTable;
 
 // ttf_parser::OutlineBuilder — f32 font units
 struct OutlineBuilder {
@@ -67,10 +70,12 @@ public:
 	bool outline_glyph(uint16_t glyph_id, OutlineBuilder &builder) const;
 	// ttf-parser's `tables().cmap.is_some()`; the reference refuses fonts without one (metadata.rs:104-107)
 	bool has_cmap() const { return has_cmap_; }
-	// glyph outlines this reader can emit: `glyf` + `loca`.  A font whose outlines live in `CFF ` / `CFF2`
-	// (ttf-parser renders those through curve_to) is refused at load time instead of yielding empty glyphs.
+	// glyph outlines this reader can emit: `glyf` + `loca`, or `CFF ` charstrings (ttf-parser's order: glyf first).
+	// A font whose outlines live in a table this reader cannot walk (`CFF2`, or a `CFF ` table it fails to parse)
+	// is refused at load time instead of yielding empty glyphs.
 	bool has_glyf_outlines() const { return !glyf_.empty() && !loca_.empty(); }
-	bool has_cff_outlines() const { return has_cff_; }
+	bool has_cff_outlines() const { return cff_ != nullptr; }
+	bool has_unsupported_outlines() const { return !has_glyf_outlines() && !cff_ && cff_unreadable_; }
 	// Face::names() (src/font/metadata.rs:92-97): every record of the `name` table in table order as
 	// (name_id, Name::to_string().unwrap_or_default()): UTF-16BE records of the Unicode platform and of
 	// the Windows platform (encodings 0 and 1) decoded to UTF-8, every other record an empty string.
@@ -92,7 +97,8 @@ private:
 	Bytes hmtx_, loca_, glyf_, name_;
 	std::vector<CmapSubtable> cmap_;
 	uint16_t units_per_em_ = 0, num_glyphs_ = 0, num_hmetrics_ = 0;
-	bool loca_long_ = false, has_cmap_ = false, has_cff_ = false;
+	bool loca_long_ = false, has_cmap_ = false, cff_unreadable_ = false;
+	std::shared_ptr<const CffTable> cff_;
 	size_t loca_entries_ = 0;
 
 	friend struct GlyfWalker;
