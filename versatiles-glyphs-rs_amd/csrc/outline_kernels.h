@@ -57,9 +57,11 @@ extern "C" {
 int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
                           uint8_t *cmd_open, uint32_t *error_flag, hipStream_t stream);
 // counts: one per command; cmd_box: double4 per command
+// cmd_mask: one 64-bit word per command (cubics: first candidates of the leaves, read again by emit_segments);
+// error_flag bit 2: a cubic broke its depth bound
 int vgsdf_outline_count(const vgsdf::OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *cmd_off,
                         uint32_t n_glyphs, const double *scale, const double *shift_x, uint32_t *counts, void *cmd_box,
-                        hipStream_t stream);
+                        unsigned long long *cmd_mask, uint32_t *error_flag, hipStream_t stream);
 // pt_local: n_cmds + n_glyphs + 1 entries; error_flag: one zeroed word
 int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const uint8_t *cmd_open, const double *scale,
                         const double *shift_x, uint32_t n_glyphs, const uint32_t *counts, uint32_t *pt_local, const void *cmd_box,
@@ -75,5 +77,5 @@ int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, 
                                 const double *shift_x,
                                 const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,
                                 const vgsdf::GlyphDesc *descs, const vgsdf::PlanHeader *hdr, unsigned long long seg_cap,
-                                double *seg /* records {sx, sy, ex, ey} */, hipStream_t stream);
+                                double *seg /* records {sx, sy, ex, ey} */, const unsigned long long *cmd_mask, hipStream_t stream);
 }

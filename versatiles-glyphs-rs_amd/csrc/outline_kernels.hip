@@ -241,19 +241,94 @@ __device__ __forceinline__ int32_t to_i32(double v)
 // (1 +- 1e-6) tolerance^2 at levels L - 1 and L, the tree IS complete, the command appends exactly 2^L points
 // and point r is the end point of the leaf reached from the root by the bits of r (most significant first) —
 // the same midpoint operations on the same f64 values as the sequential walk, in any order.  (All 323 k
-// quadratics of the 21 fixture fonts qualify; L is 4 or 5 for most.)  Everything else — a quadratic inside the
-// margin or with absurd coordinates, every cubic, commands of a glyph whose transform is not monotone — keeps
-// the sequential walk in its own lane.
+// quadratics of the 21 fixture fonts qualify; L is 4 or 5 for most.)
+//
+// A cubic's tree is adaptive, but its depth is bounded: with the second differences D1 = s - 2a + b, D2 = a - 2b + e
+// the halves have (D1 / 4, (D1 + D2) / 8) and ((D1 + D2) / 8, D2 / 4), so M = max |component| of them falls at
+// least 4-fold per level, and the reference's flatness measure (b + a) - (s + e) = -(D1 + D2) has a squared
+// length <= 8 M^2: every node at depth Dmax = the first level with 16^Dmax >= 1.01 * 800 M0^2 is flat.  The
+// 2^Dmax <= 64 "candidate" leaves of the complete tree of that depth are dealt out like a quadratic's points;
+// the lane of a candidate item walks down from the root with the reference's own flatness test at every node
+// and emits each adaptive leaf once, at the leaf's FIRST candidate.  A 64-bit mask of those first candidates per
+// command (first flattening pass -> second) turns a candidate into the point's index: the number of mask bits
+// below it.
+//
+// Everything else — a quadratic inside the margin, a cubic deeper than 6 levels, absurd coordinates, commands of a
+// glyph whose transform is not monotone — keeps the sequential walk, one lane of the wave at a time.
 //
 // A wave therefore deals the points of its 64 commands out to its 64 lanes in ITEMS of up to 8 consecutive
 // points (a subtree of depth <= 3; a line is an item of one point), 64 items per round: a curve of 32 points is
 // four items and no longer keeps 63 lanes waiting, and the walk down to a subtree's root is shared by its 8 leaves.
 // ---------------------------------------------------------------------------------------
+constexpr uint32_t kCubicFlag = 0x80000000u;
 struct WaveQuads {
-	double sx[64], sy[64], cx[64], cy[64], ex[64], ey[64];
-	uint32_t pre[65]; // exclusive sums of the commands' parallel point counts
-	uint32_t lev[64];
+	double sx[64], sy[64], cx[64], cy[64], ex[64], ey[64]; // quadratic: s, c, e; cubic: s, a, e
+	double bx[64], by[64];                                 // cubic: second control point
+	uint32_t pre[65];             // exclusive sums of the commands' items
+	uint32_t lev[64];             // depth of the (candidate) tree; kCubicFlag: cubic
+	unsigned long long mask[64];  // cubic: first candidates of the adaptive leaves
 };
+
+struct CubicNode {
+	double s0, s1, a0, a1, b0, b1, e0, e1;
+};
+__device__ __forceinline__ bool cubic_flat(const CubicNode &n)
+{
+	const double dx = (n.b0 + n.a0) - (n.s0 + n.e0); // ring.rs:171-172
+	const double dy = (n.b1 + n.a1) - (n.s1 + n.e1);
+	return dx * dx + dy * dy <= kTolSq;
+}
+__device__ __forceinline__ void cubic_split(const CubicNode &n, CubicNode &l, CubicNode &r)
+{
+	const double p01x = (n.s0 + n.a0) / 2.0, p01y = (n.s1 + n.a1) / 2.0; // ring.rs:176-182
+	const double p12x = (n.a0 + n.b0) / 2.0, p12y = (n.a1 + n.b1) / 2.0;
+	const double p23x = (n.b0 + n.e0) / 2.0, p23y = (n.b1 + n.e1) / 2.0;
+	const double p012x = (p01x + p12x) / 2.0, p012y = (p01y + p12y) / 2.0;
+	const double p123x = (p12x + p23x) / 2.0, p123y = (p12y + p23y) / 2.0;
+	const double mx = (p012x + p123x) / 2.0, my = (p012y + p123y) / 2.0;
+	l = CubicNode{n.s0, n.s1, p01x, p01y, p012x, p012y, mx, my};
+	r = CubicNode{mx, my, p123x, p123y, p23x, p23y, n.e0, n.e1};
+}
+// depth bound of a cubic's adaptive tree (see above); false: not for the parallel rounds
+__device__ __forceinline__ bool cubic_parallel_depth(const CubicNode &n, uint32_t &depth)
+{
+	const double d1x = n.s0 - 2.0 * n.a0 + n.b0, d1y = n.s1 - 2.0 * n.a1 + n.b1;
+	const double d2x = n.a0 - 2.0 * n.b0 + n.e0, d2y = n.a1 - 2.0 * n.b1 + n.e1;
+	const double M = fmax(fmax(fabs(d1x), fabs(d1y)), fmax(fabs(d2x), fabs(d2y)));
+	const double m = fmax(fmax(fmax(fabs(n.s0), fabs(n.s1)), fmax(fabs(n.a0), fabs(n.a1))),
+	                      fmax(fmax(fabs(n.b0), fabs(n.b1)), fmax(fabs(n.e0), fabs(n.e1))));
+	depth = 0;
+	if (!(M <= 1.0e6 && m <= 1.0e6)) // (false for NaN / inf)
+		return false;
+	const double need = 1.01 * 800.0 * M * M;
+	double v = 1.0;
+	uint32_t D = 0;
+	while (v < need) {
+		v *= 16.0;
+		if (++D > 6)
+			return false;
+	}
+	depth = D;
+	return true;
+}
+// the adaptive leaves of the subtree under `n` that spans the candidates [c, c + 2^DL): emit(first candidate, end point)
+template <int DL, class Emit>
+__device__ __forceinline__ void cubic_subtree(const CubicNode &n, uint32_t c, bool &bound_broken, Emit &emit)
+{
+	if constexpr (DL == 0) {
+		bound_broken |= !cubic_flat(n); // (cannot happen: the depth bound; the batch is refused if it does)
+		emit(c, n.e0, n.e1);
+	} else {
+		if (cubic_flat(n)) {
+			emit(c, n.e0, n.e1);
+			return;
+		}
+		CubicNode l, r;
+		cubic_split(n, l, r);
+		cubic_subtree<DL - 1>(l, c, bound_broken, emit);
+		cubic_subtree<DL - 1>(r, c + (1u << (DL - 1)), bound_broken, emit);
+	}
+}
 
 // points this command hands to the parallel rounds (0: none or sequential), its tree depth
 __device__ __forceinline__ uint32_t quad_parallel_points(double sx, double sy, double cx, double cy, double ex, double ey, uint32_t &lev)
@@ -294,14 +369,16 @@ __device__ __forceinline__ void quad_subtree(double sx, double sy, double cx, do
 
 constexpr uint32_t kItemDepth = 3; // an item = a subtree of up to 2^3 leaves
 
-// The parallel rounds of one wave.  `n_par` / `lev` / control points: this lane's command (n_par = 0: it takes no
-// part).  point(owner lane, index of the point inside its command, x, y) is called once per point, in order inside
-// an item; done(owner lane) after the last point of an item.
-template <class Point, class Done>
-__device__ __forceinline__ void wave_parallel_points(WaveQuads &w, uint32_t lane, uint32_t n_par, uint32_t lev, double sx, double sy,
-                                                     double cx, double cy, double ex, double ey, Point point, Done done)
+// The parallel rounds of one wave.  `n_items` / `lev` / control points: this lane's command (n_items = 0: it takes
+// no part; for a cubic lev carries kCubicFlag and (cx, cy) / (bx, by) are its two control points).
+// point(owner lane, index of the point inside its command, x, y) is called once per point of a line or quadratic,
+// cubic_point(owner lane, first candidate of the leaf, x, y) once per leaf of a cubic, in order inside an item;
+// done(owner lane) after the last point of an item.  Returns false if a cubic broke its depth bound.
+template <class Point, class CubicPoint, class Done>
+__device__ __forceinline__ bool wave_parallel_points(WaveQuads &w, uint32_t lane, uint32_t n_items, uint32_t lev, double sx, double sy,
+                                                     double cx, double cy, double bx, double by, double ex, double ey, Point point,
+                                                     CubicPoint cubic_point, Done done)
 {
-	const uint32_t n_items = n_par == 0 ? 0u : (n_par > (1u << kItemDepth) ? n_par >> kItemDepth : 1u);
 	uint32_t total;
 	const uint32_t excl = wave_exclusive_sum(n_items, total);
 	w.pre[lane] = excl;
@@ -309,16 +386,49 @@ __device__ __forceinline__ void wave_parallel_points(WaveQuads &w, uint32_t lane
 		w.pre[64] = total;
 	w.lev[lane] = lev;
 	w.sx[lane] = sx, w.sy[lane] = sy, w.cx[lane] = cx, w.cy[lane] = cy, w.ex[lane] = ex, w.ey[lane] = ey;
+	w.bx[lane] = bx, w.by[lane] = by;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
+	bool bound_broken = false;
 	for (uint32_t q = lane; q < total; q += 64) {
 		uint32_t k = 0; // the last command with pre[k] <= q (commands without items share their successor's offset)
 #pragma unroll
 		for (uint32_t step = 32; step > 0; step >>= 1)
 			if (w.pre[k + step] <= q)
 				k += step;
-		const uint32_t L = w.lev[k], item = q - w.pre[k];
+		const uint32_t lv = w.lev[k], L = lv & ~kCubicFlag, item = q - w.pre[k];
 		const uint32_t Db = L < kItemDepth ? L : kItemDepth;
+		if (lv & kCubicFlag) {
+			CubicNode n{w.sx[k], w.sy[k], w.cx[k], w.cy[k], w.bx[k], w.by[k], w.ex[k], w.ey[k]};
+			auto emit = [&](uint32_t c, double x, double y) { cubic_point(k, c, x, y); };
+			bool in_item = true;
+			// down to the item's root, the bits of `item` most significant first: an ancestor that is flat is a leaf
+			// that spans this item and its neighbours; the first of them emits it
+			for (uint32_t l = L - Db; l-- > 0;) {
+				if (cubic_flat(n)) {
+					if ((item & ((2u << l) - 1u)) == 0)
+						emit(item << Db, n.e0, n.e1);
+					in_item = false;
+					break;
+				}
+				CubicNode lo, hi;
+				cubic_split(n, lo, hi);
+				n = ((item >> l) & 1u) ? hi : lo;
+			}
+			if (in_item) {
+				const uint32_t c0 = item << Db;
+				if (Db == 3)
+					cubic_subtree<3>(n, c0, bound_broken, emit);
+				else if (Db == 0)
+					cubic_subtree<0>(n, c0, bound_broken, emit);
+				else if (Db == 2)
+					cubic_subtree<2>(n, c0, bound_broken, emit);
+				else
+					cubic_subtree<1>(n, c0, bound_broken, emit);
+			}
+			done(k);
+			continue;
+		}
 		double qsx = w.sx[k], qsy = w.sy[k], qcx = w.cx[k], qcy = w.cy[k], qex = w.ex[k], qey = w.ey[k];
 		// down to the item's root: the bits of `item`, most significant first
 		for (uint32_t l = L - Db; l-- > 0;) {
@@ -348,7 +458,11 @@ __device__ __forceinline__ void wave_parallel_points(WaveQuads &w, uint32_t lane
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
+	return !bound_broken;
 }
+
+// items a command of 2^depth points / candidates hands to the parallel rounds
+__device__ __forceinline__ uint32_t items_of_depth(uint32_t depth) { return depth > kItemDepth ? 1u << (depth - kItemDepth) : 1u; }
 
 // f64 <-> unsigned key with the same order (for integer atomics on LDS)
 __device__ __forceinline__ unsigned long long f64_key(double v)
@@ -403,7 +517,9 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_count(const OutlineCm
                                                                  const uint32_t *__restrict__ cmd_off, uint32_t n_glyphs,
                                                                  const double *__restrict__ scale,
                                                                  const double *__restrict__ shift_x,
-                                                                 uint32_t *__restrict__ counts, double4 *__restrict__ cmd_box)
+                                                                 uint32_t *__restrict__ counts, double4 *__restrict__ cmd_box,
+                                                                 unsigned long long *__restrict__ cmd_mask,
+                                                                 uint32_t *__restrict__ error_flag)
 {
 	__shared__ double s_stack[kSerialStackDoubles];
 	__shared__ WaveQuads s_w;
@@ -425,42 +541,69 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_count(const OutlineCm
 	const double lx = open ? (double)cmds[i - 1].x : 0.0, ly = open ? (double)cmds[i - 1].y : 0.0;
 	const double inf = __builtin_huge_val();
 	const bool raw_boxes = (ctx & 2) == 0;
-	// parallel rounds: move_to / line_to (one point, a tree of depth 0) and the quadratics with a complete tree
-	uint32_t n_par = 0, lev = 0;
+	// parallel rounds: move_to / line_to (one point, a tree of depth 0), the quadratics with a complete tree, the
+	// cubics with a depth bound of at most 6
+	uint32_t n_par = 0, n_items = 0, lev = 0;
+	bool cubic = false;
 	if (valid && raw_boxes) {
-		if (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE)
-			n_par = 1;
-		else if (cmd.kind == CMD_QUAD && open)
+		if (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE) {
+			n_par = n_items = 1;
+		} else if (cmd.kind == CMD_QUAD && open) {
 			n_par = quad_parallel_points(lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y, lev);
+			n_items = n_par ? items_of_depth(lev) : 0u;
+		} else if (cmd.kind == CMD_CURVE && open) {
+			const CubicNode root{lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x2, (double)cmd.y2, (double)cmd.x, (double)cmd.y};
+			cubic = cubic_parallel_depth(root, lev);
+			if (cubic) {
+				n_items = items_of_depth(lev);
+				lev |= kCubicFlag;
+			}
+		}
 	}
 	s_box[0][lane] = s_box[1][lane] = f64_key(inf);
 	s_box[2][lane] = s_box[3][lane] = f64_key(-inf);
+	s_w.mask[lane] = 0;
 	{
 		double bx0 = inf, by0 = inf, bx1 = -inf, by1 = -inf; // box of the item being walked
-		wave_parallel_points(
-		    s_w, lane, n_par, lev, lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y,
-		    [&](uint32_t, uint32_t, double x, double y) {
-			    bx0 = fmin(bx0, x); // bbox.rs:64-69 (fmin / fmax skip NaN)
-			    by0 = fmin(by0, y);
-			    bx1 = fmax(bx1, x);
-			    by1 = fmax(by1, y);
+		unsigned long long leaves = 0;                        // first candidates of the cubic leaves of the item
+		auto grow = [&](double x, double y) {
+			bx0 = fmin(bx0, x); // bbox.rs:64-69 (fmin / fmax skip NaN)
+			by0 = fmin(by0, y);
+			bx1 = fmax(bx1, x);
+			by1 = fmax(by1, y);
+		};
+		const bool ok = wave_parallel_points(
+		    s_w, lane, n_items, lev, lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x2, (double)cmd.y2, (double)cmd.x, (double)cmd.y,
+		    [&](uint32_t, uint32_t, double x, double y) { grow(x, y); },
+		    [&](uint32_t, uint32_t c, double x, double y) {
+			    grow(x, y);
+			    leaves |= 1ull << c;
 		    },
 		    [&](uint32_t k) {
 			    atomicMin(&s_box[0][k], f64_key(bx0));
 			    atomicMin(&s_box[1][k], f64_key(by0));
 			    atomicMax(&s_box[2][k], f64_key(bx1));
 			    atomicMax(&s_box[3][k], f64_key(by1));
+			    if (leaves)
+				    atomicOr(&s_w.mask[k], leaves);
 			    bx0 = inf, by0 = inf, bx1 = -inf, by1 = -inf;
+			    leaves = 0;
 		    });
+		if (!ok)
+			atomicOr(error_flag, 4u); // (a cubic deeper than its bound: never seen; the batch is refused rather than wrong)
 	}
-	if (valid && n_par != 0) {
+	if (cubic) {
+		n_par = (uint32_t)__builtin_popcountll(s_w.mask[lane]);
+		cmd_mask[i] = s_w.mask[lane];
+	}
+	if (valid && n_items != 0) {
 		counts[i] = n_par;
 		cmd_box[i] = make_double4(key_f64(s_box[0][lane]), key_f64(s_box[1][lane]), key_f64(s_box[2][lane]), key_f64(s_box[3][lane]));
 	}
 	// sequential walks, one lane at a time (they share the wave's work list in LDS); quad_to / curve_to on an empty
 	// ring and close() append nothing and need no walk
-	const bool walk = valid && n_par == 0 && (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE || ((cmd.kind == CMD_QUAD || cmd.kind == CMD_CURVE) && open));
-	if (valid && n_par == 0 && !walk) {
+	const bool walk = valid && n_items == 0 && (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE || ((cmd.kind == CMD_QUAD || cmd.kind == CMD_CURVE) && open));
+	if (valid && n_items == 0 && !walk) {
 		counts[i] = 0;
 		cmd_box[i] = make_double4(inf, inf, -inf, -inf);
 	}
@@ -865,7 +1008,8 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
                                                                          const uint32_t *__restrict__ cmd_ring,
                                                                          const GlyphDesc *__restrict__ descs,
                                                                          const PlanHeader *__restrict__ hdr,
-                                                                         unsigned long long seg_cap, double2 *__restrict__ seg)
+                                                                         unsigned long long seg_cap, double2 *__restrict__ seg,
+                                                                         const unsigned long long *__restrict__ cmd_mask)
 {
 	__shared__ double s_stack[kSerialStackDoubles];
 	__shared__ WaveQuads s_w;
@@ -921,12 +1065,22 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 		else if (append) // the closing segment (n - 1) returns to the first point
 			seg[2 * (base + n - 1) + 1] = make_double2(x, y);
 	};
-	uint32_t n_par = 0, lev = 0;
+	uint32_t n_items = 0, lev = 0;
+	unsigned long long mask = 0;
 	if (active && monotone) { // the same split as in the count pass
-		if (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE)
-			n_par = 1;
-		else if (cmd.kind == CMD_QUAD && open)
-			n_par = quad_parallel_points(lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y, lev);
+		if (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE) {
+			n_items = 1;
+		} else if (cmd.kind == CMD_QUAD && open) {
+			if (quad_parallel_points(lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y, lev))
+				n_items = items_of_depth(lev);
+		} else if (cmd.kind == CMD_CURVE && open) {
+			const CubicNode root{lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x2, (double)cmd.y2, (double)cmd.x, (double)cmd.y};
+			if (cubic_parallel_depth(root, lev)) {
+				n_items = items_of_depth(lev);
+				lev |= kCubicFlag;
+				mask = cmd_mask[c]; // first candidates of the leaves, from the count pass
+			}
+		}
 	}
 	s_seg0[lane] = (unsigned long long)seg0;
 	s_idx0[lane] = idx;
@@ -934,18 +1088,25 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 	s_append[lane] = r.append;
 	s_sc[lane] = sc;
 	s_dx[lane] = dx;
-	wave_parallel_points(s_w, lane, n_par, lev, lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x, (double)cmd.y,
-	                     [&](uint32_t k, uint32_t j, double x, double y) {
-		                     const double ksc = s_sc[k];
-		                     x *= ksc; // point.rs:96-99
-		                     y *= ksc;
-		                     x += s_dx[k]; // point.rs:83-86
-		                     y += 0.0;
-		                     place((size_t)s_seg0[k], s_idx0[k] + j, s_n[k], s_append[k], x, y);
-	                     },
-	                     [](uint32_t) {});
+	s_w.mask[lane] = mask;
+	auto put = [&](uint32_t k, uint32_t j, double x, double y) {
+		const double ksc = s_sc[k];
+		x *= ksc; // point.rs:96-99
+		y *= ksc;
+		x += s_dx[k]; // point.rs:83-86
+		y += 0.0;
+		place((size_t)s_seg0[k], s_idx0[k] + j, s_n[k], s_append[k], x, y);
+	};
+	(void)wave_parallel_points(
+	    s_w, lane, n_items, lev, lx, ly, (double)cmd.x1, (double)cmd.y1, (double)cmd.x2, (double)cmd.y2, (double)cmd.x, (double)cmd.y,
+	    [&](uint32_t k, uint32_t j, double x, double y) { put(k, j, x, y); },
+	    [&](uint32_t k, uint32_t cand, double x, double y) {
+		    // the leaf's index inside its command: the leaves in front of it
+		    put(k, (uint32_t)__builtin_popcountll(s_w.mask[k] & ((1ull << cand) - 1ull)), x, y);
+	    },
+	    [](uint32_t) {});
 	// sequential walks, one lane at a time (they share the wave's work list in LDS)
-	const bool walk = active && n_par == 0 && (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE || ((cmd.kind == CMD_QUAD || cmd.kind == CMD_CURVE) && open));
+	const bool walk = active && n_items == 0 && (cmd.kind == CMD_MOVE || cmd.kind == CMD_LINE || ((cmd.kind == CMD_QUAD || cmd.kind == CMD_CURVE) && open));
 	for (unsigned long long todo = __ballot(walk); todo; todo &= todo - 1) {
 		if (lane != (uint32_t)__builtin_ctzll(todo))
 			continue;
@@ -975,12 +1136,12 @@ extern "C" int vgsdf_outline_context(const OutlineCmd *cmds, const uint32_t *cmd
 
 extern "C" int vgsdf_outline_count(const OutlineCmd *cmds, const uint8_t *cmd_open, uint32_t n_cmds, const uint32_t *cmd_off,
                                    uint32_t n_glyphs, const double *scale, const double *shift_x, uint32_t *counts, void *cmd_box,
-                                   hipStream_t stream)
+                                   unsigned long long *cmd_mask, uint32_t *error_flag, hipStream_t stream)
 {
 	if (n_cmds == 0)
 		return 0;
 	hipLaunchKernelGGL(outline_count, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream, cmds,
-	                   cmd_open, n_cmds, cmd_off, n_glyphs, scale, shift_x, counts, (double4 *)cmd_box);
+	                   cmd_open, n_cmds, cmd_off, n_glyphs, scale, shift_x, counts, (double4 *)cmd_box, cmd_mask, error_flag);
 	return (int)hipGetLastError();
 }
 
@@ -1010,11 +1171,11 @@ extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cm
                                            const double *shift_x,
                                            const uint32_t *pt_local, const RingRec *rings, const uint32_t *cmd_ring,
                                            const GlyphDesc *descs, const PlanHeader *hdr, unsigned long long seg_cap, double *seg,
-                                           hipStream_t stream)
+                                           const unsigned long long *cmd_mask, hipStream_t stream)
 {
 	if (n_cmds == 0)
 		return 0;
 	hipLaunchKernelGGL(outline_emit_segments, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream,
-	                   cmds, n_cmds, cmd_open, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg);
+	                   cmds, n_cmds, cmd_open, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg, cmd_mask);
 	return (int)hipGetLastError();
 }

@@ -116,7 +116,7 @@ struct FePending {
 
 struct FrontEnd {
 	// device: inputs, per-command / per-ring intermediates, results of measure + plan, the resident batch
-	DevBuf cmds, meta, cmd_open, counts, pt_local, cmd_box, rings, cmd_ring, rects_hdr, descs, tiles, flag;
+	DevBuf cmds, meta, cmd_open, counts, pt_local, cmd_box, cmd_mask, rings, cmd_ring, rects_hdr, descs, tiles, flag;
 	DevBuf seg, out, boxes; // seg: records {sx, sy, ex, ey}
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
@@ -134,7 +134,7 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes,
+		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &cmd_mask, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes,
 		                  &h_rects, &h_stage})
 			b->release();
 	}
@@ -795,7 +795,7 @@ int fe_launch_emit(vgsdf_ctx *ctx, FrontEnd &fe)
 	const FeDev d = fe_dev(fe);
 	int e = vgsdf_outline_emit_segments(d.cmds, p.n_cmds, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, (const uint32_t *)fe.pt_local.p,
 	                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d.descs, d.hdr,
-	                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, ctx->stream);
+	                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, (const unsigned long long *)fe.cmd_mask.p, ctx->stream);
 	if (e == 0 && p.span)
 		e = vgsdf_launch_chunk_boxes(d.descs, p.n, (const double *)fe.seg.p, (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2,
 		                             (const double *)fe.seg.p + 3, 4, fe.boxes.p, d.hdr, (unsigned long long)fe.seg_cap, ctx->stream);
@@ -896,6 +896,7 @@ static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out
 	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.pt_local.ensure(4 * ((size_t)n_cmds + n + 2)));
 	FE_TRY(fe.cmd_box.ensure(32 * (size_t)(n_cmds + 1)));
+	FE_TRY(fe.cmd_mask.ensure(8 * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.rings.ensure(sizeof(vgsdf::RingRec) * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.cmd_ring.ensure(4 * (size_t)(n_cmds + 1)));
 	p.hdr_off = align_up(sizeof(vgsdf::OutlineRect) * (size_t)n, 16); // rects and totals: one block, one read-back
@@ -937,7 +938,7 @@ static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out
 	}
 	FE_KERNEL(vgsdf_outline_context(d.cmds, d.cmd_off, d.scale, n, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
 	FE_KERNEL(vgsdf_outline_count(d.cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, d.cmd_off, n, d.scale, d.shift,
-	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, st));
+	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, (unsigned long long *)fe.cmd_mask.p, (uint32_t *)fe.flag.p, st));
 	FE_KERNEL(vgsdf_outline_rings(d.cmds, d.cmd_off, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, n,
 	                              (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_local.p,
 	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d.rects,
@@ -992,6 +993,10 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	if (hdr.error & 2u) {
 		ctx->err = "vgsdf_outlines_prepare: unknown command kind";
 		return VGSDF_E_ARG;
+	}
+	if (hdr.error & 4u) {
+		ctx->err = "vgsdf_outlines_prepare: internal error (a cubic exceeded its subdivision depth bound)";
+		return VGSDF_E_HIP;
 	}
 	if (hdr.error) {
 		ctx->err = "vgsdf_outlines_prepare: a glyph flattens to more than 2^28 points, the batch to more than 2^32 - 1 segments, or a "
