@@ -310,6 +310,28 @@ def main():
     if shard_info:
         out["config"]["shard"] = shard_info
 
+    # ---- two batches in flight (reported beside the headline, never as `value`): the same launches alternating
+    # between two contexts = two streams, so the tail of one launch overlaps the ramp of the next — what a caller
+    # with more than one batch to render gets (FontManager does this with its two lanes)
+    if world == 1 and not args.sharded:
+        c2 = vg.SdfContext(local_rank)
+        c2.set_variant(args.variant)
+        d2 = c2.upload(hb.batch)
+        for _ in range(8):
+            db.launch(); d2.launch()
+        ctx.sync(); c2.sync()
+        t2 = time.perf_counter()
+        for i in range(steps):
+            (db if i % 2 == 0 else d2).launch()
+        ctx.sync(); c2.sync()
+        e2 = time.perf_counter() - t2
+        out["two_in_flight"] = {
+            "ms_per_step": e2 / steps * 1e3, "glyphs_per_s": st["n_glyphs"] * steps / e2, "steps": steps,
+            "note": "the timed steps launched alternately on two contexts (two HIP streams, each with its own resident copy "
+                    "of the batch and its own output); wall clock around launches + both synchronisations",
+        }
+        d2.free(); c2.close()
+
     # ---- CPU baseline: oracle raster on the same tessellated batch, host cores ---------
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
