@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-two-in-flight", action="store_true",
+                    help="skip the side measurement with two batches in flight (profiling runs: overlapping launches "
+                         "would distort the per-kernel durations)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of the other font workloads")
     ap.add_argument("--synthetic-outlines", type=int, default=0, help="outlines per rank for --workload synthetic")
     args = ap.parse_args()
@@ -313,7 +316,7 @@ def main():
     # ---- two batches in flight (reported beside the headline, never as `value`): the same launches alternating
     # between two contexts = two streams, so the tail of one launch overlaps the ramp of the next — what a caller
     # with more than one batch to render gets (FontManager does this with its two lanes)
-    if world == 1 and not args.sharded:
+    if world == 1 and not args.sharded and not args.no_two_in_flight:
         c2 = vg.SdfContext(local_rank)
         c2.set_variant(args.variant)
         d2 = c2.upload(hb.batch)

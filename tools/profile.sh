@@ -7,10 +7,10 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-e2e --no-configs $*"  # >= 50 ms of launches: the average is not a cold one
+BENCH="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-e2e --no-configs --no-two-in-flight $*"  # >= 50 ms of launches: the average is not a cold one
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 # PMC passes: counters only (never combined with other trace domains on this pool)
-PMC="python3 bench.py --steps 3 --warmup 1 --min-ms 0 --no-cpu-baseline --no-e2e --no-configs $*"
+PMC="python3 bench.py --steps 3 --warmup 1 --min-ms 0 --no-cpu-baseline --no-e2e --no-configs --no-two-in-flight $*"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMC > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $PMC > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $PMC > $OUT/sq.log 2>&1 || true
