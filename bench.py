@@ -104,8 +104,9 @@ def time_resident(ctx, db, steps, warmup, min_ms):
     for _ in range(max(warmup, 0)):
         db.launch()
     ctx.sync()
-    est = db.time(max(1, min(steps, 10))) / max(1, min(steps, 10))  # ms per launch (untimed probe)
-    k = max(steps, int(min_ms / max(est, 1e-6)) + 1)
+    probe = max(1, min(steps, 50))
+    est = db.time(probe) / probe  # ms per launch (untimed probe; the first launches of a run are slower than the rest)
+    k = max(steps, int(1.15 * min_ms / max(est, 1e-6)) + 1)
     return k, est
 
 
