@@ -166,6 +166,21 @@ int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_r
  * vgsdf_outlines_render_into does.  in->cmds and out_bitmaps must stay valid and untouched in between
  * (out_bitmaps may be NULL: no raster is enqueued, wait then equals vgsdf_outlines_prepare). */
 int vgsdf_outlines_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *out_bitmaps, size_t out_capacity);
+/* The same commands in their compact form for the upload: one kind byte per command and only the coordinates the kind
+ * carries, in callback order (move_to / line_to: x y; quad_to: x1 y1 x y; curve_to: x1 y1 x2 y2 x y; close: none) —
+ * about 12 bytes per command of a TrueType font instead of 28.  dat_off[g] .. dat_off[g + 1] is glyph g's range of
+ * `coords` (dat_off[0] = 0); it must match the kinds (VGSDF_E_ARG otherwise).  Everything else as
+ * vgsdf_outlines_submit; collect with vgsdf_outlines_wait. */
+typedef struct {
+	uint32_t n_glyphs;
+	const uint32_t *cmd_off; /* [n_glyphs + 1] into kinds */
+	const uint32_t *dat_off; /* [n_glyphs + 1] into coords */
+	const uint8_t *kinds;    /* [cmd_off[n_glyphs]] 0..4 = move / line / quad / curve / close */
+	const float *coords;     /* [dat_off[n_glyphs]] */
+	const double *scale;     /* [n_glyphs] */
+	const double *shift_x;   /* [n_glyphs] */
+} vgsdf_outlines_packed;
+int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in, uint8_t *out_bitmaps, size_t out_capacity);
 int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
 /* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */
 int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey);

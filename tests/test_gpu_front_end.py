@@ -126,6 +126,46 @@ def test_two_submissions_in_flight_on_two_contexts(vg, fira_oracle):
         c.close()
 
 
+def test_packed_upload_form_equals_the_record_form(vg, fira_oracle):
+    """vgsdf_outlines_submit_packed (kind bytes + only the coordinates a kind carries, what FontManager uploads)
+    gives the rects, segments and bitmaps of the 28-byte records: a font, and streams with cubics, closes, commands on
+    empty rings and an unknown kind; offsets that do not match the kinds are refused."""
+    ref, c = vg.SdfContext(0), vg.SdfContext(0)
+    M, L, Q, C3, Z = 0, 1, 2, 3, 4
+    cmd_off, cmds, scale, shift, _ = record(vg, fira_oracle, range(0x20, 0x600))
+    extra = [(0, 0, 0, 0, 100, 100, M), (300, 500, 700, 500, 900, 100, C3), (0, 0, 0, 0, 500, -300, L), (0,) * 6 + (Z,),
+             (10, 10, 0, 0, 20, 20, Q), (0, 0, 0, 0, 0, 0, L), (0, 0, 0, 0, 400, 0, L), (600, 300, 0, 0, 400, 600, Q), (0, 0, 0, 0, 0, 600, L),
+             (0,) * 6 + (Z,), (0,) * 6 + (Z,)]
+    cmds2 = np.concatenate([cmds, np.array(extra, dtype=vg.OUTLINE_CMD_DTYPE)])
+    cmd_off2 = np.concatenate([cmd_off, [len(cmds) + 4, len(cmds) + 9, len(cmds2)]]).astype(np.uint32)
+    scale2 = np.concatenate([scale, [0.024, 0.024, 0.024]])
+    shift2 = np.concatenate([shift, [0.0, 0.125, -0.25]])
+    rects, ob, ns = ref.outlines_prepare(cmd_off2, cmds2, scale2, shift2)
+    want_out = ref.outlines_render()
+    want_off, want_segs = ref.outlines_segments()
+    dat_off, kinds, coords = vg.SdfContext.pack_outlines(cmd_off2, cmds2)
+    assert len(coords) * 4 + len(kinds) < 0.5 * cmds2.nbytes   # the point of the form
+    for _ in range(2):
+        c.outlines_submit_packed(cmd_off2, dat_off, kinds, coords, scale2, shift2, ob + 64)
+        r2, out, ob2, ns2 = c.outlines_wait()
+        assert r2.tobytes() == rects.tobytes() and (ob2, ns2) == (ob, ns)
+        assert out is not None and out.tobytes() == want_out.tobytes()
+        off2, segs2 = c.outlines_segments()
+        assert off2.tobytes() == want_off.tobytes() and segs2.tobytes() == want_segs.tobytes()
+    bad = dat_off.copy()
+    bad[5:] -= 2                                                # glyph 4 is given two coordinates too few
+    c.outlines_submit_packed(cmd_off2, bad, kinds, coords[:-2], scale2, shift2, ob + 64)
+    with pytest.raises(vg.VgsdfError, match="dat_off"):
+        c.outlines_wait()
+    kinds_bad = kinds.copy()
+    kinds_bad[3] = 9                                            # none of the five callbacks
+    c.outlines_submit_packed(cmd_off2, dat_off, kinds_bad, coords, scale2, shift2, ob + 64)
+    with pytest.raises(vg.VgsdfError):
+        c.outlines_wait()
+    ref.close()
+    c.close()
+
+
 def test_arbitrary_command_streams(oracle, vg, ctx):
     # streams ttf-parser never emits: curve_to, quad_to on an empty ring, line_to starting a
     # ring, missing close, degenerate rings, repeated closes; rings via the oracle's RingBuilder

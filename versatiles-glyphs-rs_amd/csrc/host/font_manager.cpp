@@ -693,38 +693,65 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 	const double t1 = now_s();
 	timings_.tessellate_s += t1 - t0;
 
-	// merge in task order
-	uint32_t n_jobs = 0, n_cmds = 0;
+	// merge in task order, into the compact upload form (a kind byte per command + the coordinates its kind carries)
+	uint32_t n_jobs = 0, n_cmds = 0, n_floats = 0;
 	G.slice_cmd.resize(slices.size());
+	G.slice_dat.resize(slices.size());
 	for (size_t i = 0; i < slices.size(); i++) {
 		OSlice &s = slices[i];
 		const OutlineBatch &l = workers_[s.worker].olocal;
 		s.g_job = n_jobs;
 		G.slice_cmd[i] = n_cmds;
+		G.slice_dat[i] = n_floats;
 		n_jobs += s.job1 - s.job0;
 		n_cmds += l.cmd_off[s.job1] - l.cmd_off[s.job0];
+		n_floats += l.dat_off[s.job1] - l.dat_off[s.job0];
 	}
 	G.n_jobs = n_jobs;
 	MergedOutlines &m = G.m;
 	m.jobs.resize(n_jobs);
 	m.cmd_off.resize((size_t)n_jobs + 1);
-	m.cmds.ensure((size_t)n_cmds + 1);
+	m.dat_off.resize((size_t)n_jobs + 1);
+	m.kinds.ensure((size_t)n_cmds + 1);
+	m.coords.ensure((size_t)n_floats + 1);
 	m.scale.resize(n_jobs);
 	m.shift_x.resize(n_jobs);
 	m.cmd_off[0] = 0;
+	m.dat_off[0] = 0;
 	tp.run(slices.size(), [&](size_t i, unsigned) {
 		const OSlice &s = slices[i];
 		const OutlineBatch &l = workers_[s.worker].olocal;
-		const uint32_t lc0 = l.cmd_off[s.job0];
-		const size_t nc = l.cmd_off[s.job1] - lc0;
-		if (nc)
-			std::memcpy(m.cmds.data() + G.slice_cmd[i], l.cmds.data() + lc0, nc * sizeof(vgsdf_outline_cmd));
+		const uint32_t lc0 = l.cmd_off[s.job0], lc1 = l.cmd_off[s.job1], ld0 = l.dat_off[s.job0];
+		uint8_t *kinds = m.kinds.data() + G.slice_cmd[i];
+		float *co = m.coords.data() + G.slice_dat[i];
+		for (uint32_t c = lc0; c < lc1; c++) {
+			const vgsdf_outline_cmd &q = l.cmds[c];
+			*kinds++ = (uint8_t)q.kind;
+			switch (q.kind) {
+			case 0:
+			case 1:
+				co[0] = q.x, co[1] = q.y;
+				co += 2;
+				break;
+			case 2:
+				co[0] = q.x1, co[1] = q.y1, co[2] = q.x, co[3] = q.y;
+				co += 4;
+				break;
+			case 3:
+				co[0] = q.x1, co[1] = q.y1, co[2] = q.x2, co[3] = q.y2, co[4] = q.x, co[5] = q.y;
+				co += 6;
+				break;
+			default:
+				break;
+			}
+		}
 		for (uint32_t j = s.job0; j < s.job1; j++) {
 			const uint32_t g = s.g_job + (j - s.job0);
 			m.jobs[g] = l.jobs[j];
 			m.scale[g] = l.scale[j];
 			m.shift_x[g] = l.shift_x[j];
 			m.cmd_off[g + 1] = G.slice_cmd[i] + (l.cmd_off[j + 1] - lc0);
+			m.dat_off[g + 1] = G.slice_dat[i] + (l.dat_off[j + 1] - ld0);
 		}
 	});
 	timings_.pack_s += now_s() - t1;

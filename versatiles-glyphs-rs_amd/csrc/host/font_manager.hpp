@@ -226,7 +226,7 @@ private:
 	struct FeGroup {
 		size_t g0 = 0, g1 = 0;
 		std::vector<OSlice> slices;
-		std::vector<uint32_t> slice_ci, slice_cmd;
+		std::vector<uint32_t> slice_ci, slice_cmd, slice_dat;
 		MergedOutlines m;
 		std::vector<vgsdf_rect> rects;
 		HostBuffer<uint8_t> out{true};

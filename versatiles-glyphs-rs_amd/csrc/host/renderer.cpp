@@ -240,6 +240,7 @@ bool Renderer::record(const Face &face, uint32_t index, OutlineBatch &batch)
 	job.advance = advance;
 	batch.jobs.push_back(job);
 	batch.cmd_off.push_back((uint32_t)batch.cmds.size());
+	batch.dat_off.push_back(batch.dat_off.back() + rec.n_floats());
 	batch.scale.push_back(scale);
 	batch.shift_x.push_back(((double)advance - advance_float) / 2.0); // :130
 	return true;
@@ -255,7 +256,7 @@ vgsdf_ctx *Renderer::lane_ctx(int lane) const
 	return ctx2_;
 }
 
-void Renderer::submit_outlines(int lane, const vgsdf_outlines &v, HostBuffer<uint8_t> &out) const
+void Renderer::submit_outlines(int lane, const vgsdf_outlines_packed &v, HostBuffer<uint8_t> &out) const
 {
 	if (mode_ != Mode::Hip)
 		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
@@ -268,8 +269,8 @@ void Renderer::submit_outlines(int lane, const vgsdf_outlines &v, HostBuffer<uin
 		if (out.capacity() == 0)
 			out.ensure((size_t)v.n_glyphs * 448 + 4096);
 		std::lock_guard<std::mutex> lock(mu_);
-		if (vgsdf_outlines_submit(c, &v, out.data(), out.capacity()) != VGSDF_OK)
-			throw std::runtime_error(std::string("vgsdf_outlines_submit: ") + vgsdf_last_error(c));
+		if (vgsdf_outlines_submit_packed(c, &v, out.data(), out.capacity()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_submit_packed: ") + vgsdf_last_error(c));
 	} catch (...) {
 		lane_mu_[lane].unlock();
 		throw;
@@ -308,8 +309,20 @@ void Renderer::render_outlines(const vgsdf_outlines &v, std::vector<vgsdf_rect> 
 	out_bytes = n_segments = 0;
 	if (v.n_glyphs == 0)
 		return;
-	submit_outlines(0, v, out);
-	wait_outlines(0, rects, out, out_bytes, n_segments, v.n_glyphs);
+	if (mode_ != Mode::Hip)
+		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
+	std::lock_guard<std::mutex> lane(lane_mu_[0]);
+	std::lock_guard<std::mutex> lock(mu_);
+	if (out.capacity() == 0)
+		out.ensure((size_t)v.n_glyphs * 448 + 4096);
+	int rendered = 0;
+	if (vgsdf_outlines_render_into(ctx_, &v, rects.data(), out.data(), out.capacity(), &out_bytes, &n_segments, &rendered) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_outlines_render_into: ") + vgsdf_last_error(ctx_));
+	if (!rendered && out_bytes) {
+		out.ensure((size_t)out_bytes + 1);
+		if (vgsdf_outlines_render(ctx_, out.data()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(ctx_));
+	}
 }
 
 void Renderer::render_batch(const GlyphBatch &batch, uint8_t *out) const

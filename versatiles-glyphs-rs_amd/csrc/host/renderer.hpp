@@ -149,6 +149,7 @@ struct PackedBatch {
 struct OutlineBatch {
 	std::vector<GlyphJob> jobs;        // one per glyph the reference returns Some(..) for
 	std::vector<uint32_t> cmd_off{0};  // [jobs + 1]
+	std::vector<uint32_t> dat_off{0};  // [jobs + 1]: coordinates the commands carry (2 / 4 / 6 / 0 per move or line / quad / curve / close)
 	std::vector<vgsdf_outline_cmd> cmds;
 	std::vector<double> scale, shift_x;
 
@@ -156,6 +157,7 @@ struct OutlineBatch {
 	{
 		jobs.clear();
 		cmd_off.assign(1, 0);
+		dat_off.assign(1, 0);
 		cmds.clear();
 		scale.clear();
 		shift_x.clear();
@@ -172,18 +174,22 @@ struct OutlineBatch {
 	}
 };
 
-// The merged batch handed to the device: commands in page-locked memory (DMA without staging).
+// The merged batch handed to the device, in the compact upload form (vgsdf_outlines_packed: one kind byte per
+// command plus the coordinates its kind carries) in page-locked memory (DMA without staging).
 struct MergedOutlines {
 	std::vector<GlyphJob> jobs;
-	std::vector<uint32_t> cmd_off{0};
-	HostBuffer<vgsdf_outline_cmd> cmds{true};
+	std::vector<uint32_t> cmd_off{0}, dat_off{0};
+	HostBuffer<uint8_t> kinds{true};
+	HostBuffer<float> coords{true};
 	std::vector<double> scale, shift_x;
-	vgsdf_outlines view() const
+	vgsdf_outlines_packed view() const
 	{
-		vgsdf_outlines o;
+		vgsdf_outlines_packed o;
 		o.n_glyphs = (uint32_t)jobs.size();
 		o.cmd_off = cmd_off.data();
-		o.cmds = cmds.data();
+		o.dat_off = dat_off.data();
+		o.kinds = kinds.data();
+		o.coords = coords.data();
 		o.scale = scale.data();
 		o.shift_x = shift_x.data();
 		return o;
@@ -194,13 +200,15 @@ struct MergedOutlines {
 class CommandRecorder final : public OutlineBuilder {
 public:
 	explicit CommandRecorder(std::vector<vgsdf_outline_cmd> &out) : out_(out) {}
-	void move_to(float x, float y) override { push(0, 0, 0, 0, 0, x, y); }
-	void line_to(float x, float y) override { push(1, 0, 0, 0, 0, x, y); }
-	void quad_to(float x1, float y1, float x, float y) override { push(2, x1, y1, 0, 0, x, y); }
-	void curve_to(float x1, float y1, float x2, float y2, float x, float y) override { push(3, x1, y1, x2, y2, x, y); }
+	void move_to(float x, float y) override { n_floats_ += 2, push(0, 0, 0, 0, 0, x, y); }
+	void line_to(float x, float y) override { n_floats_ += 2, push(1, 0, 0, 0, 0, x, y); }
+	void quad_to(float x1, float y1, float x, float y) override { n_floats_ += 4, push(2, x1, y1, 0, 0, x, y); }
+	void curve_to(float x1, float y1, float x2, float y2, float x, float y) override { n_floats_ += 6, push(3, x1, y1, x2, y2, x, y); }
 	void close() override { push(4, 0, 0, 0, 0, 0, 0); }
+	uint32_t n_floats() const { return n_floats_; } // coordinates the recorded commands carry
 
 private:
+	uint32_t n_floats_ = 0;
 	void push(uint32_t kind, float x1, float y1, float x2, float y2, float x, float y)
 	{
 		vgsdf_outline_cmd c;
@@ -250,7 +258,7 @@ public:
 	// upload, front-end and raster and returns; wait collects.  A caller that alternates the lanes keeps the GPU
 	// busy while it records the next batch and encodes the previous one.  `batch` (its command array) and `out`
 	// must stay untouched between the two calls; a lane is held from submit to wait.
-	void submit_outlines(int lane, const vgsdf_outlines &batch, HostBuffer<uint8_t> &out) const;
+	void submit_outlines(int lane, const vgsdf_outlines_packed &batch, HostBuffer<uint8_t> &out) const;
 	void wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
 	                   uint64_t &n_segments, uint32_t n_glyphs) const;
 

@@ -56,6 +56,12 @@ extern "C" {
 // error_flag: one zeroed word; bit 1 is raised for a command kind that is none of the five callbacks
 int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
                           uint8_t *cmd_open, uint32_t *error_flag, hipStream_t stream);
+// the same for commands that arrive packed (one kind byte per command, coords: 2 / 4 / 6 / 0 floats per move or line / quad /
+// curve / close, dat_off[n_glyphs + 1]: every glyph's range of coords); expands them into cmds_out; error_flag bit 3: the
+// offsets do not match the kinds
+int vgsdf_outline_context_packed(const uint8_t *kinds, const float *coords, const uint32_t *dat_off, const uint32_t *cmd_off,
+                                 const double *scale, uint32_t n_glyphs, vgsdf::OutlineCmd *cmds_out, uint8_t *cmd_open,
+                                 uint32_t *error_flag, hipStream_t stream);
 // counts: one per command; cmd_box: double4 per command
 // cmd_mask: one 64-bit word per command (cubics: first candidates of the leaves, read again by emit_segments);
 // error_flag bit 2: a cubic broke its depth bound

@@ -479,9 +479,15 @@ __device__ __forceinline__ double key_f64(unsigned long long k)
 // context: one wave per glyph.  Is the ring non-empty when command c arrives?  (quad_to / curve_to are ignored
 // on an empty ring, ring_builder.rs:83-85,99-101.)
 // ---------------------------------------------------------------------------------------
+// PACKED: the commands arrive as one kind byte each plus only the coordinates their kind carries (move / line 2
+// floats, quad 4, curve 6, close none: ~12 bytes per command of a TrueType font instead of 28 on the PCIe link);
+// this pass also expands them into the OutlineCmd records every later pass reads (`cmds_out`).
+template <bool PACKED>
 __global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restrict__ cmds, const uint32_t *__restrict__ cmd_off,
                                                       const double *__restrict__ scale, uint32_t n_glyphs,
-                                                      uint8_t *__restrict__ cmd_open, uint32_t *__restrict__ error_flag)
+                                                      uint8_t *__restrict__ cmd_open, uint32_t *__restrict__ error_flag,
+                                                      const uint8_t *__restrict__ kinds, const float *__restrict__ coords,
+                                                      const uint32_t *__restrict__ dat_off, OutlineCmd *__restrict__ cmds_out)
 {
 	const uint32_t g = blockIdx.x, lane = threadIdx.x;
 	if (g >= n_glyphs)
@@ -492,9 +498,42 @@ __global__ __launch_bounds__(64) void outline_context(const OutlineCmd *__restri
 	// the bounding boxes on the transformed points
 	const uint8_t odd = (sc > 0.0 && sc < __builtin_huge_val()) ? 0 : 2;
 	bool carry = false;
+	uint32_t d_at = 0, d_end = 0; // this glyph's coordinates: coords[d_at, d_end)
+	if constexpr (PACKED) {
+		d_at = dat_off[g];
+		d_end = dat_off[g + 1];
+	}
 	for (uint32_t base = c0; base < c1; base += 64) {
 		const uint32_t c = base + lane;
-		const uint32_t k = c < c1 ? cmds[c].kind : 0xFFu;
+		uint32_t k = 0xFFu;
+		if constexpr (PACKED) {
+			if (c < c1)
+				k = kinds[c];
+			const uint32_t nf = k <= CMD_LINE ? 2u : (k == CMD_QUAD ? 4u : (k == CMD_CURVE ? 6u : 0u));
+			uint32_t total;
+			const uint32_t at = d_at + wave_exclusive_sum(nf, total);
+			d_at += total;
+			if (c < c1) {
+				OutlineCmd o;
+				o.x1 = o.y1 = o.x2 = o.y2 = o.x = o.y = 0.0f;
+				o.kind = k;
+				if (at + nf > d_end) { // the offsets do not match the kinds: nothing is read past the glyph's range
+					atomicOr(error_flag, 8u);
+					o.kind = CMD_CLOSE;
+					k = CMD_CLOSE;
+				} else if (nf == 2) {
+					o.x = coords[at], o.y = coords[at + 1];
+				} else if (nf == 4) {
+					o.x1 = coords[at], o.y1 = coords[at + 1], o.x = coords[at + 2], o.y = coords[at + 3];
+				} else if (nf == 6) {
+					o.x1 = coords[at], o.y1 = coords[at + 1], o.x2 = coords[at + 2], o.y2 = coords[at + 3];
+					o.x = coords[at + 4], o.y = coords[at + 5];
+				}
+				cmds_out[c] = o;
+			}
+		} else {
+			k = c < c1 ? cmds[c].kind : 0xFFu;
+		}
 		const bool open = ring_open_before(k, lane, carry);
 		if (c < c1) {
 			cmd_open[c] = (uint8_t)((open ? 1 : 0) | odd);
@@ -1130,7 +1169,19 @@ extern "C" int vgsdf_outline_context(const OutlineCmd *cmds, const uint32_t *cmd
 {
 	if (n_glyphs == 0)
 		return 0;
-	hipLaunchKernelGGL(outline_context, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, scale, n_glyphs, cmd_open, error_flag);
+	hipLaunchKernelGGL(outline_context<false>, dim3(n_glyphs), dim3(64), 0, stream, cmds, cmd_off, scale, n_glyphs, cmd_open, error_flag,
+	                   (const uint8_t *)nullptr, (const float *)nullptr, (const uint32_t *)nullptr, (OutlineCmd *)nullptr);
+	return (int)hipGetLastError();
+}
+
+extern "C" int vgsdf_outline_context_packed(const uint8_t *kinds, const float *coords, const uint32_t *dat_off, const uint32_t *cmd_off,
+                                            const double *scale, uint32_t n_glyphs, OutlineCmd *cmds_out, uint8_t *cmd_open,
+                                            uint32_t *error_flag, hipStream_t stream)
+{
+	if (n_glyphs == 0)
+		return 0;
+	hipLaunchKernelGGL(outline_context<true>, dim3(n_glyphs), dim3(64), 0, stream, (const OutlineCmd *)nullptr, cmd_off, scale, n_glyphs,
+	                   cmd_open, error_flag, kinds, coords, dat_off, cmds_out);
 	return (int)hipGetLastError();
 }
 

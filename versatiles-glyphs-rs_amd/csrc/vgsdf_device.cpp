@@ -116,7 +116,7 @@ struct FePending {
 
 struct FrontEnd {
 	// device: inputs, per-command / per-ring intermediates, results of measure + plan, the resident batch
-	DevBuf cmds, meta, cmd_open, counts, pt_local, cmd_box, cmd_mask, rings, cmd_ring, rects_hdr, descs, tiles, flag;
+	DevBuf cmds, kinds, coords, meta, cmd_open, counts, pt_local, cmd_box, cmd_mask, rings, cmd_ring, rects_hdr, descs, tiles, flag;
 	DevBuf seg, out, boxes; // seg: records {sx, sy, ex, ey}
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
@@ -134,7 +134,7 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &cmd_mask, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes,
+		for (DevBuf *b : {&cmds, &kinds, &coords, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &cmd_mask, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes,
 		                  &h_rects, &h_stage})
 			b->release();
 	}
@@ -624,7 +624,7 @@ int vgsdf_batch_upload(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 void *vgsdf_host_alloc(size_t bytes)
 {
 	void *p = nullptr;
-	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { // every device of the process may read / write it
 		(void)hipGetLastError();
 		return nullptr;
 	}
@@ -821,12 +821,24 @@ hipError_t fe_ensure_segs(FrontEnd &fe, size_t want, uint32_t n_glyphs)
 }
 } // namespace
 
-static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out, size_t spec_cap)
+// the two input forms of a submission: 28-byte command records, or kinds + coordinates (vgsdf_outlines_packed)
+struct FeInput {
+	uint32_t n_glyphs = 0;
+	const uint32_t *cmd_off = nullptr;
+	const double *scale = nullptr, *shift_x = nullptr;
+	const vgsdf_outline_cmd *cmds = nullptr;
+	const uint32_t *dat_off = nullptr;
+	const uint8_t *kinds = nullptr;
+	const float *coords = nullptr;
+	bool packed = false;
+};
+
+static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_t spec_cap)
 {
 	const double tr0 = fe_now();
 	if (!ctx)
 		return VGSDF_E_ARG;
-	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x))) {
+	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x || (in->packed && !in->dat_off)))) {
 		ctx->err = "vgsdf_outlines: NULL argument";
 		return VGSDF_E_ARG;
 	}
@@ -843,9 +855,26 @@ static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out
 			return VGSDF_E_ARG;
 		}
 	const uint32_t n_cmds = n ? in->cmd_off[n] : 0;
-	if (n_cmds && !in->cmds) {
+	if (n_cmds && (in->packed ? !in->kinds : !in->cmds)) {
 		ctx->err = "vgsdf_outlines: NULL command array";
 		return VGSDF_E_ARG;
+	}
+	uint32_t n_floats = 0;
+	if (in->packed && n) {
+		if (in->dat_off[0] != 0) {
+			ctx->err = "vgsdf_outlines: dat_off[0] must be 0";
+			return VGSDF_E_ARG;
+		}
+		for (uint32_t g = 0; g < n; g++)
+			if (in->dat_off[g + 1] < in->dat_off[g]) {
+				ctx->err = "vgsdf_outlines: dat_off not monotone";
+				return VGSDF_E_ARG;
+			}
+		n_floats = in->dat_off[n];
+		if (n_floats && !in->coords) {
+			ctx->err = "vgsdf_outlines: NULL coordinate array";
+			return VGSDF_E_ARG;
+		}
 	}
 	// (the command kinds are checked on the device: the kernels treat an unknown kind as a no-op and the context
 	// pass raises the batch's error flag, so nothing unsafe runs and the host need not walk the commands)
@@ -889,7 +918,8 @@ static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out
 	p.span_budget = sb ? (uint32_t)std::max(1, std::atoi(sb)) : 16u;
 	FE_TRY(fe.cmds.ensure(sizeof(vgsdf::OutlineCmd) * (size_t)(n_cmds + 1)));
 	// per-glyph inputs (scale, shift, command offsets) travel as ONE block through pinned staging
-	const size_t meta_scale = 0, meta_shift = 8 * (size_t)n, meta_off = 16 * (size_t)n, meta_bytes = meta_off + 4 * (size_t)(n + 1);
+	const size_t meta_scale = 0, meta_shift = 8 * (size_t)n, meta_off = 16 * (size_t)n, meta_dat = meta_off + 4 * (size_t)(n + 1);
+	const size_t meta_bytes = meta_dat + (in->packed ? 4 * (size_t)(n + 1) : 0);
 	FE_TRY(fe.meta.ensure(meta_bytes + 16));
 	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
@@ -911,13 +941,23 @@ static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out
 	FE_TRY(fe_ensure_tiles(fe, 2 * (size_t)n + 1024));
 	FE_TRY(fe_ensure_segs(fe, 12 * (size_t)n_cmds + 4096, n));
 
-	if (n_cmds)
+	if (in->packed) {
+		FE_TRY(fe.kinds.ensure((size_t)n_cmds + 16));
+		FE_TRY(fe.coords.ensure(4 * (size_t)n_floats + 16));
+		if (n_cmds)
+			FE_TRY(hipMemcpyAsync(fe.kinds.p, in->kinds, (size_t)n_cmds, hipMemcpyHostToDevice, st));
+		if (n_floats)
+			FE_TRY(hipMemcpyAsync(fe.coords.p, in->coords, 4 * (size_t)n_floats, hipMemcpyHostToDevice, st));
+	} else if (n_cmds) {
 		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
+	}
 	{
 		uint8_t *hm = (uint8_t *)fe.h_stage.p;
 		std::memcpy(hm + meta_scale, in->scale, 8 * (size_t)n);
 		std::memcpy(hm + meta_shift, in->shift_x, 8 * (size_t)n);
 		std::memcpy(hm + meta_off, in->cmd_off, 4 * (size_t)(n + 1));
+		if (in->packed)
+			std::memcpy(hm + meta_dat, in->dat_off, 4 * (size_t)(n + 1));
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
 	}
 	FE_TRY(hipMemsetAsync(fe.flag.p, 0, 16, st));
@@ -936,7 +976,12 @@ static int fe_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *spec_out
 		const size_t guess = fe.last_spans ? (size_t)fe.last_spans + fe.last_spans / 2 + 256 : fe.tile_cap;
 		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
-	FE_KERNEL(vgsdf_outline_context(d.cmds, d.cmd_off, d.scale, n, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
+	if (in->packed)
+		FE_KERNEL(vgsdf_outline_context_packed((const uint8_t *)fe.kinds.p, (const float *)fe.coords.p,
+		                                       (const uint32_t *)((const uint8_t *)fe.meta.p + meta_dat), d.cmd_off, d.scale, n,
+		                                       (vgsdf::OutlineCmd *)fe.cmds.p, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
+	else
+		FE_KERNEL(vgsdf_outline_context(d.cmds, d.cmd_off, d.scale, n, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
 	FE_KERNEL(vgsdf_outline_count(d.cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, d.cmd_off, n, d.scale, d.shift,
 	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, (unsigned long long *)fe.cmd_mask.p, (uint32_t *)fe.flag.p, st));
 	FE_KERNEL(vgsdf_outline_rings(d.cmds, d.cmd_off, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, n,
@@ -992,6 +1037,10 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + p.hdr_off, sizeof hdr);
 	if (hdr.error & 2u) {
 		ctx->err = "vgsdf_outlines_prepare: unknown command kind";
+		return VGSDF_E_ARG;
+	}
+	if (hdr.error & 8u) {
+		ctx->err = "vgsdf_outlines: dat_off does not match the command kinds";
 		return VGSDF_E_ARG;
 	}
 	if (hdr.error & 4u) {
@@ -1084,6 +1133,17 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	return VGSDF_OK;
 }
 
+static FeInput fe_input(const vgsdf_outlines *in)
+{
+	FeInput f;
+	f.n_glyphs = in->n_glyphs;
+	f.cmd_off = in->cmd_off;
+	f.scale = in->scale;
+	f.shift_x = in->shift_x;
+	f.cmds = in->cmds;
+	return f;
+}
+
 int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint64_t *out_bytes,
                            uint64_t *n_segments)
 {
@@ -1091,13 +1151,39 @@ int vgsdf_outlines_prepare(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect 
 		ctx->err = "vgsdf_outlines_prepare: NULL argument";
 		return VGSDF_E_ARG;
 	}
-	const int rc = fe_submit(ctx, in, nullptr, 0);
+	if (ctx && !in) {
+		ctx->err = "vgsdf_outlines: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	FeInput f;
+	if (in)
+		f = fe_input(in);
+	const int rc = fe_submit(ctx, in ? &f : nullptr, nullptr, 0);
 	return rc != VGSDF_OK ? rc : fe_wait(ctx, rects_out, out_bytes, n_segments, nullptr);
 }
 
 int vgsdf_outlines_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *out_bitmaps, size_t out_capacity)
 {
-	return fe_submit(ctx, in, out_bitmaps, out_bitmaps ? out_capacity : 0);
+	FeInput f;
+	if (in)
+		f = fe_input(in);
+	return fe_submit(ctx, in ? &f : nullptr, out_bitmaps, out_bitmaps ? out_capacity : 0);
+}
+
+int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in, uint8_t *out_bitmaps, size_t out_capacity)
+{
+	FeInput f;
+	if (in) {
+		f.n_glyphs = in->n_glyphs;
+		f.cmd_off = in->cmd_off;
+		f.scale = in->scale;
+		f.shift_x = in->shift_x;
+		f.dat_off = in->dat_off;
+		f.kinds = in->kinds;
+		f.coords = in->coords;
+		f.packed = true;
+	}
+	return fe_submit(ctx, in ? &f : nullptr, out_bitmaps, out_bitmaps ? out_capacity : 0);
 }
 
 int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered)
@@ -1112,7 +1198,10 @@ int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_r
 		ctx->err = "vgsdf_outlines_render_into: NULL argument";
 		return VGSDF_E_ARG;
 	}
-	const int rc = fe_submit(ctx, in, out_bitmaps, out_bitmaps ? out_capacity : 0);
+	FeInput f;
+	if (in)
+		f = fe_input(in);
+	const int rc = fe_submit(ctx, in ? &f : nullptr, out_bitmaps, out_bitmaps ? out_capacity : 0);
 	return rc != VGSDF_OK ? rc : fe_wait(ctx, rects_out, out_bytes, n_segments, rendered);
 }
 

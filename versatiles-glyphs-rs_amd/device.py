@@ -37,11 +37,16 @@ class _COutlines(C.Structure):
                 ("shift_x", C.c_void_p)]
 
 
+class _COutlinesPacked(C.Structure):
+    _fields_ = [("n_glyphs", C.c_uint32), ("cmd_off", C.c_void_p), ("dat_off", C.c_void_p), ("kinds", C.c_void_p),
+                ("coords", C.c_void_p), ("scale", C.c_void_p), ("shift_x", C.c_void_p)]
+
+
 VGSDF_SYMBOLS = [
     "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
-    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
+    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
 ]
 
 _lib = None
@@ -83,6 +88,7 @@ def load_library():
         L.vgsdf_outlines_render_into.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
         L.vgsdf_outlines_submit.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_wait.argtypes = [vp, vp, vp, vp, vp]
+        L.vgsdf_outlines_submit_packed.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -271,6 +277,41 @@ class SdfContext:
             raise MemoryError("vgsdf_host_alloc")
         co = _COutlines(n, keep["cmd_off"].ctypes.data, keep["cmds"].ctypes.data, keep["scale"].ctypes.data, keep["shift"].ctypes.data)
         rc = L.vgsdf_outlines_submit(self._h, C.byref(co), host, capacity)
+        if rc != 0:
+            L.vgsdf_host_free(host)
+            self._check(rc)
+        self._inflight = (keep, host, capacity, n)
+
+    @staticmethod
+    def pack_outlines(cmd_off, cmds):
+        """28-byte command records -> (dat_off, kinds, coords) of vgsdf_outlines_packed"""
+        cmds = np.ascontiguousarray(cmds, dtype=OUTLINE_CMD_DTYPE)
+        kinds = cmds["kind"].astype(np.uint8)
+        nf = np.select([cmds["kind"] <= 1, cmds["kind"] == 2, cmds["kind"] == 3], [2, 4, 6], 0).astype(np.int64)
+        at = np.concatenate([[0], np.cumsum(nf)])
+        coords = np.zeros(int(at[-1]), dtype=np.float32)
+        for fields, k in ((("x", "y"), (0, 1)), (("x1", "y1", "x", "y"), (2,)), (("x1", "y1", "x2", "y2", "x", "y"), (3,))):
+            sel = np.isin(cmds["kind"], k)
+            for j, f in enumerate(fields):
+                coords[at[:-1][sel] + j] = cmds[f][sel]
+        dat_off = at[np.asarray(cmd_off, dtype=np.int64)].astype(np.uint32)
+        return dat_off, kinds, coords
+
+    def outlines_submit_packed(self, cmd_off, dat_off, kinds, coords, scale, shift_x, capacity: int):
+        """outlines_submit for the compact upload form (vgsdf_outlines_packed)"""
+        L = load_library()
+        keep = {
+            "cmd_off": np.ascontiguousarray(cmd_off, dtype=np.uint32), "dat_off": np.ascontiguousarray(dat_off, dtype=np.uint32),
+            "kinds": np.ascontiguousarray(kinds, dtype=np.uint8), "coords": np.ascontiguousarray(coords, dtype=np.float32),
+            "scale": np.ascontiguousarray(scale, dtype=np.float64), "shift": np.ascontiguousarray(shift_x, dtype=np.float64),
+        }
+        n = len(keep["scale"])
+        host = L.vgsdf_host_alloc(max(capacity, 1))
+        if not host:
+            raise MemoryError("vgsdf_host_alloc")
+        co = _COutlinesPacked(n, keep["cmd_off"].ctypes.data, keep["dat_off"].ctypes.data, keep["kinds"].ctypes.data,
+                              keep["coords"].ctypes.data, keep["scale"].ctypes.data, keep["shift"].ctypes.data)
+        rc = L.vgsdf_outlines_submit_packed(self._h, C.byref(co), host, capacity)
         if rc != 0:
             L.vgsdf_host_free(host)
             self._check(rc)
