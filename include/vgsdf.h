@@ -170,7 +170,9 @@ int vgsdf_outlines_submit(vgsdf_ctx *ctx, const vgsdf_outlines *in, uint8_t *out
  * carries, in callback order (move_to / line_to: x y; quad_to: x1 y1 x y; curve_to: x1 y1 x2 y2 x y; close: none) —
  * about 12 bytes per command of a TrueType font instead of 28.  dat_off[g] .. dat_off[g + 1] is glyph g's range of
  * `coords` (dat_off[0] = 0); it must match the kinds (VGSDF_E_ARG otherwise).  Everything else as
- * vgsdf_outlines_submit; collect with vgsdf_outlines_wait. */
+ * vgsdf_outlines_submit; collect with vgsdf_outlines_wait.  When the arrays sit back to back in ONE block from
+ * vgsdf_host_alloc() in the order scale | shift_x | cmd_off | dat_off | (pad to a multiple of 8 bytes) | coords | kinds
+ * the library uploads them with a single copy. */
 typedef struct {
 	uint32_t n_glyphs;
 	const uint32_t *cmd_off; /* [n_glyphs + 1] into kinds */

@@ -710,20 +710,15 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 	G.n_jobs = n_jobs;
 	MergedOutlines &m = G.m;
 	m.jobs.resize(n_jobs);
-	m.cmd_off.resize((size_t)n_jobs + 1);
-	m.dat_off.resize((size_t)n_jobs + 1);
-	m.kinds.ensure((size_t)n_cmds + 1);
-	m.coords.ensure((size_t)n_floats + 1);
-	m.scale.resize(n_jobs);
-	m.shift_x.resize(n_jobs);
+	m.layout(n_jobs, n_cmds, n_floats);
 	m.cmd_off[0] = 0;
 	m.dat_off[0] = 0;
 	tp.run(slices.size(), [&](size_t i, unsigned) {
 		const OSlice &s = slices[i];
 		const OutlineBatch &l = workers_[s.worker].olocal;
 		const uint32_t lc0 = l.cmd_off[s.job0], lc1 = l.cmd_off[s.job1], ld0 = l.dat_off[s.job0];
-		uint8_t *kinds = m.kinds.data() + G.slice_cmd[i];
-		float *co = m.coords.data() + G.slice_dat[i];
+		uint8_t *kinds = m.kinds + G.slice_cmd[i];
+		float *co = m.coords + G.slice_dat[i];
 		for (uint32_t c = lc0; c < lc1; c++) {
 			const vgsdf_outline_cmd &q = l.cmds[c];
 			*kinds++ = (uint8_t)q.kind;

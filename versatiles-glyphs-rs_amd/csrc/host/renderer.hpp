@@ -175,23 +175,41 @@ struct OutlineBatch {
 };
 
 // The merged batch handed to the device, in the compact upload form (vgsdf_outlines_packed: one kind byte per
-// command plus the coordinates its kind carries) in page-locked memory (DMA without staging).
+// command plus the coordinates its kind carries).  All arrays live back to back in ONE page-locked block, in the
+// order vgsdf.h names for a single-copy upload: scale | shift_x | cmd_off | dat_off | (pad to 8) | coords | kinds.
 struct MergedOutlines {
 	std::vector<GlyphJob> jobs;
-	std::vector<uint32_t> cmd_off{0}, dat_off{0};
-	HostBuffer<uint8_t> kinds{true};
-	HostBuffer<float> coords{true};
-	std::vector<double> scale, shift_x;
+	HostBuffer<uint8_t> blob{true};
+	uint32_t n_jobs = 0;
+	double *scale = nullptr, *shift_x = nullptr;
+	uint32_t *cmd_off = nullptr, *dat_off = nullptr;
+	float *coords = nullptr;
+	uint8_t *kinds = nullptr;
+	void layout(uint32_t jobs_n, uint32_t n_cmds, uint32_t n_floats)
+	{
+		n_jobs = jobs_n;
+		const size_t n = jobs_n;
+		const size_t o_shift = 8 * n, o_cmd = 16 * n, o_dat = o_cmd + 4 * (n + 1);
+		const size_t o_coords = (o_dat + 4 * (n + 1) + 7) & ~(size_t)7, o_kinds = o_coords + 4 * (size_t)n_floats;
+		blob.ensure(o_kinds + n_cmds + 16);
+		uint8_t *b = blob.data();
+		scale = reinterpret_cast<double *>(b);
+		shift_x = reinterpret_cast<double *>(b + o_shift);
+		cmd_off = reinterpret_cast<uint32_t *>(b + o_cmd);
+		dat_off = reinterpret_cast<uint32_t *>(b + o_dat);
+		coords = reinterpret_cast<float *>(b + o_coords);
+		kinds = b + o_kinds;
+	}
 	vgsdf_outlines_packed view() const
 	{
 		vgsdf_outlines_packed o;
-		o.n_glyphs = (uint32_t)jobs.size();
-		o.cmd_off = cmd_off.data();
-		o.dat_off = dat_off.data();
-		o.kinds = kinds.data();
-		o.coords = coords.data();
-		o.scale = scale.data();
-		o.shift_x = shift_x.data();
+		o.n_glyphs = n_jobs;
+		o.cmd_off = cmd_off;
+		o.dat_off = dat_off;
+		o.kinds = kinds;
+		o.coords = coords;
+		o.scale = scale;
+		o.shift_x = shift_x;
 		return o;
 	}
 };

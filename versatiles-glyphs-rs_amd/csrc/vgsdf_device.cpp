@@ -920,7 +920,15 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	// per-glyph inputs (scale, shift, command offsets) travel as ONE block through pinned staging
 	const size_t meta_scale = 0, meta_shift = 8 * (size_t)n, meta_off = 16 * (size_t)n, meta_dat = meta_off + 4 * (size_t)(n + 1);
 	const size_t meta_bytes = meta_dat + (in->packed ? 4 * (size_t)(n + 1) : 0);
-	FE_TRY(fe.meta.ensure(meta_bytes + 16));
+	// packed input whose arrays sit back to back in one page-locked block, in the order of the device's own layout
+	// (scale | shift_x | cmd_off | dat_off | pad to 8 | coords | kinds): ONE copy instead of three
+	const size_t blob_coords = (meta_bytes + 7) & ~(size_t)7, blob_kinds = blob_coords + 4 * (size_t)n_floats;
+	const size_t blob_bytes = blob_kinds + n_cmds;
+	const uint8_t *hb = (const uint8_t *)in->scale;
+	const bool blob = in->packed && (const uint8_t *)in->shift_x == hb + meta_shift && (const uint8_t *)in->cmd_off == hb + meta_off &&
+	                  (const uint8_t *)in->dat_off == hb + meta_dat && (const uint8_t *)in->coords == hb + blob_coords &&
+	                  in->kinds == hb + blob_kinds && is_pinned(hb, blob_bytes);
+	FE_TRY(fe.meta.ensure((blob ? blob_bytes : meta_bytes) + 16));
 	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
 	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
@@ -941,17 +949,25 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	FE_TRY(fe_ensure_tiles(fe, 2 * (size_t)n + 1024));
 	FE_TRY(fe_ensure_segs(fe, 12 * (size_t)n_cmds + 4096, n));
 
-	if (in->packed) {
+	const uint8_t *d_kinds = nullptr;
+	const float *d_coords = nullptr;
+	if (blob) {
+		FE_TRY(hipMemcpyAsync(fe.meta.p, hb, blob_bytes, hipMemcpyHostToDevice, st));
+		d_coords = (const float *)((const uint8_t *)fe.meta.p + blob_coords);
+		d_kinds = (const uint8_t *)fe.meta.p + blob_kinds;
+	} else if (in->packed) {
 		FE_TRY(fe.kinds.ensure((size_t)n_cmds + 16));
 		FE_TRY(fe.coords.ensure(4 * (size_t)n_floats + 16));
 		if (n_cmds)
 			FE_TRY(hipMemcpyAsync(fe.kinds.p, in->kinds, (size_t)n_cmds, hipMemcpyHostToDevice, st));
 		if (n_floats)
 			FE_TRY(hipMemcpyAsync(fe.coords.p, in->coords, 4 * (size_t)n_floats, hipMemcpyHostToDevice, st));
+		d_kinds = (const uint8_t *)fe.kinds.p;
+		d_coords = (const float *)fe.coords.p;
 	} else if (n_cmds) {
 		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
 	}
-	{
+	if (!blob) {
 		uint8_t *hm = (uint8_t *)fe.h_stage.p;
 		std::memcpy(hm + meta_scale, in->scale, 8 * (size_t)n);
 		std::memcpy(hm + meta_shift, in->shift_x, 8 * (size_t)n);
@@ -977,7 +993,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
 	if (in->packed)
-		FE_KERNEL(vgsdf_outline_context_packed((const uint8_t *)fe.kinds.p, (const float *)fe.coords.p,
+		FE_KERNEL(vgsdf_outline_context_packed(d_kinds, d_coords,
 		                                       (const uint32_t *)((const uint8_t *)fe.meta.p + meta_dat), d.cmd_off, d.scale, n,
 		                                       (vgsdf::OutlineCmd *)fe.cmds.p, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
 	else
