@@ -9,9 +9,11 @@ ROOT = Path(__file__).resolve().parent.parent
 tag = sys.argv[1]
 src = ROOT / "gpurun_out" / f"prof_{tag}_front_end"
 rows = []
+import os
 for pat in ("trace/**/*kernel_stats.csv", "trace/**/*memory_copy_stats.csv"):
-    for f in glob.glob(str(src / pat), recursive=True):
-        rows += list(csv.DictReader(open(f)))
+    files = sorted(glob.glob(str(src / pat), recursive=True), key=os.path.getmtime)
+    if files:  # (gpurun merges every run into the same directory: take the newest)
+        rows += list(csv.DictReader(open(files[-1])))
 front = ("outline_context", "outline_count", "outline_rings", "outline_plan", "outline_emit_segments", "sdf_chunk_boxes")
 lines = [f"# rocprofv3 --kernel-trace --memory-copy-trace --stats — end-to-end run with the device front-end "
          f"(tools/e2e_time.py noto_regular fe), {tag}", "",

@@ -15,11 +15,13 @@ dst.mkdir(exist_ok=True)
 
 
 def rows(pattern):
-    out = []
-    for f in glob.glob(str(src / pattern), recursive=True):
-        with open(f) as fh:
-            out += list(csv.DictReader(fh))
-    return out
+    """rows of the NEWEST file that matches (gpurun merges every run into the same directory)"""
+    import os
+    files = sorted(glob.glob(str(src / pattern), recursive=True), key=os.path.getmtime)
+    if not files:
+        return []
+    with open(files[-1]) as fh:
+        return list(csv.DictReader(fh))
 
 
 lines = [f"# rocprofv3 summary — {tag} ({workload}, kernel variant {variant})", ""]
@@ -27,7 +29,8 @@ stats = rows("trace/**/*kernel_stats.csv")
 lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
 for r in stats:
     lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
-for f in glob.glob(str(src / "trace/**/*kernel_stats.csv"), recursive=True):
+import os
+for f in sorted(glob.glob(str(src / "trace/**/*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
     (dst / f"{tag}_kernel_stats.csv").write_text(Path(f).read_text())
 tr = rows("trace/**/*kernel_trace.csv")
 if tr:
