@@ -130,3 +130,23 @@ def test_hip_renderer_fails_loudly_without_gpu(vg):
     assert "no CPU fallback" in str(e.value)
     with pytest.raises(vg.VgsdfError):
         vg.SdfContext(0)
+
+
+@pytest.mark.timeout(300)
+def test_worker_pool_survives_many_short_forks(vg):
+    """the host pool polls briefly before it sleeps: hundreds of back-to-back fork/joins (three per render), with the
+    gaps between renders longer and shorter than the polling window, must neither hang nor lose a block"""
+    import time
+    m = vg.FontManager(True)
+    m.set_threads(8, 16)
+    fid = m.add_font_with_name("Fira Sans Regular", [FIRA])
+    r = vg.Renderer.new_dummy()
+    w = vg.DummyWriter()
+    m.render_glyphs(w, r)
+    want = {k: len(v) for k, v in w.files.items()}
+    for i in range(120):
+        w = vg.DummyWriter()
+        m.render_glyphs(w, r)
+        assert {k: len(v) for k, v in w.files.items()} == want
+        if i % 10 == 0:
+            time.sleep(0.002)   # let the workers fall asleep on the condition variable
