@@ -708,6 +708,13 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 	const double sc = scale[g], dx = shift_x[g];
 	const double inf = __builtin_huge_val();
 	const bool raw_boxes = sc > 0.0 && sc < inf; // (the count pass made the same decision)
+	// What the passes hand each other (point offsets, ring of a command, ring accepted) also stays in LDS for glyphs
+	// of up to kRingsLds commands (every glyph of the fixture fonts): no round trip through memory between the passes
+	constexpr uint32_t kRingsLds = 1024;
+	__shared__ uint32_t s_pt[kRingsLds + 1], s_ring[kRingsLds];
+	__shared__ uint8_t s_acc[kRingsLds];
+	const bool in_lds = c1 - c0 <= kRingsLds;
+	auto pt_at = [&](uint32_t c) { return in_lds ? s_pt[c - c0] : pt_local[c + g]; }; // c in [c0, c1]
 
 	// ---- pass 1 ----
 	uint32_t pbase = 0;
@@ -718,13 +725,18 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 		const uint32_t cnt = valid ? counts[c] : 0u;
 		uint32_t total;
 		const uint32_t excl = wave_exclusive_sum(cnt, total);
-		if (valid)
+		if (valid) {
 			pt_local[c + g] = pbase + excl; // (one slot per command plus one end slot per glyph)
+			if (in_lds)
+				s_pt[c - c0] = pbase + excl;
+		}
 		pbase += total;
 		total64 += total;
 	}
 	if (lane == 0) {
 		pt_local[c1 + g] = pbase;
+		if (in_lds)
+			s_pt[c1 - c0] = pbase;
 		if (total64 > (1ull << 28)) // (also keeps the 32-bit point offsets of a glyph exact)
 			atomicOr(error_flag, 1u);
 	}
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 	// ---- pass 2 ----
 	auto ring_rec = [&](uint32_t ra, uint32_t rb) {
 		RingRec r;
-		const uint32_t a = pt_local[ra + g], b = pt_local[rb + g]; // points [a, b) of the glyph
+		const uint32_t a = pt_at(ra), b = pt_at(rb); // points [a, b) of the glyph
 		r.pt_first = a;
 		r.pt_count = b - a;
 		r.append = 0;
@@ -765,8 +777,11 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 		const unsigned long long below = sb & ((1ull << lane) - 1ull);
 		const uint32_t start_before = below ? base + (uint32_t)(63 - __builtin_clzll(below)) : last_start;
 		const uint32_t start_here = starts ? c : start_before;
-		if (valid)
+		if (valid) {
 			cmd_ring[c] = have_after ? start_here : 0xFFFFFFFFu;
+			if (in_lds)
+				s_ring[c - c0] = have_after ? start_here : 0xFFFFFFFFu;
+		}
 		RingRec rec;
 		rec.accepted = 0;
 		uint32_t segs = 0;
@@ -781,6 +796,8 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 		if (ends) {
 			rec.seg_local = seg_base + seg_excl;
 			rings[start_before] = rec; // ring records live at the index of the command that opened them
+			if (in_lds)
+				s_acc[start_before - c0] = (uint8_t)rec.accepted;
 		}
 		seg_base += tot_segs;
 		n_rings_acc += tot_acc;
@@ -798,6 +815,8 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 			n_rings_acc++;
 		}
 		rings[last_start] = rec;
+		if (in_lds)
+			s_acc[last_start - c0] = (uint8_t)rec.accepted;
 	}
 	seg_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_base);
 	n_rings_acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_rings_acc);
@@ -806,8 +825,8 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 	// ---- pass 3 ----
 	double minx = inf, miny = inf, maxx = -inf, maxy = -inf;
 	for (uint32_t c = c0 + lane; c < c1; c += 64) {
-		const uint32_t rs = cmd_ring[c];
-		if (rs != 0xFFFFFFFFu && rings[rs].accepted) {
+		const uint32_t rs = in_lds ? s_ring[c - c0] : cmd_ring[c];
+		if (rs != 0xFFFFFFFFu && (in_lds ? s_acc[rs - c0] != 0 : rings[rs].accepted != 0)) {
 			const double4 bx = cmd_box[c];
 			minx = fmin(minx, bx.x);
 			miny = fmin(miny, bx.y);
@@ -939,15 +958,38 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	bool bad = false;
 	const uint32_t per = (n_glyphs + kPlanThreads - 1) / kPlanThreads;
 	const uint32_t g_lo = min(tid * per, n_glyphs), g_hi = min(g_lo + per, n_glyphs);
+	// a run of up to four glyphs (batches of <= 4096 glyphs: a font) stays in registers with its classification, so
+	// the rects are read once and classified once for both passes
+	constexpr uint32_t kKeep = 4;
+	const bool kept = per <= kKeep;
+	OutlineRect kr[kKeep];
+	uint32_t kcls[kKeep], kT[kKeep], kn[kKeep], kw[kKeep];
+#pragma unroll
+	for (uint32_t j = 0; j < kKeep; j++) {
+		kr[j].x0 = kr[j].y0 = 0;
+		kr[j].w = kr[j].h = kr[j].n_segments = kr[j].has_raster = 0;
+		kcls[j] = kT[j] = kn[j] = kw[j] = 0;
+		if (kept && g_lo + j < g_hi) {
+			kr[j] = rects[g_lo + j];
+			classify(kr[j], kcls[j], kT[j], kn[j], kw[j]);
+		}
+	}
 	{
 		unsigned long long my_s = 0, my_p = 0;
-		for (uint32_t g = g_lo; g < g_hi; g++) {
-			const OutlineRect r = rects[g];
+		auto sum_one = [&](const OutlineRect &r) {
 			if (r.has_raster) {
 				my_s += r.n_segments;
 				my_p += (unsigned long long)r.w * r.h;
 				bad |= (unsigned long long)r.w * r.h > 0xFFFFFFFFull - 256ull;
 			}
+		};
+		if (kept) {
+#pragma unroll
+			for (uint32_t j = 0; j < kKeep; j++)
+				sum_one(kr[j]);
+		} else {
+			for (uint32_t g = g_lo; g < g_hi; g++)
+				sum_one(rects[g]);
 		}
 		unsigned long long tot_s, tot_p;
 		unsigned long long so = block_exclusive_sum(my_s, s_wave, tot_s);
@@ -956,8 +998,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 			s_carry[0] = tot_s;
 			s_carry[1] = tot_p;
 		}
-		for (uint32_t g = g_lo; g < g_hi; g++) {
-			const OutlineRect r = rects[g];
+		auto desc_one = [&](uint32_t g, const OutlineRect &r, uint32_t cls, uint32_t nspans, uint32_t weight) {
 			const unsigned long long px = r.has_raster ? (unsigned long long)r.w * r.h : 0ull;
 			const unsigned long long segs = r.has_raster ? r.n_segments : 0u;
 			GlyphDesc d;
@@ -971,10 +1012,21 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 			descs[g] = d;
 			so += segs;
 			po += px;
-			uint32_t cls, T, nspans, weight;
-			classify(r, cls, T, nspans, weight);
 			if (nspans)
 				atomicAdd(&s_hist[cls][plan_bucket(weight)], nspans);
+		};
+		if (kept) {
+#pragma unroll
+			for (uint32_t j = 0; j < kKeep; j++)
+				if (g_lo + j < g_hi)
+					desc_one(g_lo + j, kr[j], kcls[j], kn[j], kw[j]);
+		} else {
+			for (uint32_t g = g_lo; g < g_hi; g++) {
+				const OutlineRect r = rects[g];
+				uint32_t cls, T, nspans, weight;
+				classify(r, cls, T, nspans, weight);
+				desc_one(g, r, cls, nspans, weight);
+			}
 		}
 	}
 	__syncthreads();
@@ -1015,17 +1067,27 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 		hdr->ok = s_carry[0] <= seg_cap && s_carry[1] <= out_cap && s_nall == s_nmain && s_nmain <= launch_spans;
 	// pass B: entries.  One per span of T tiles: (glyph, first pixel | T) in the span list's main class, else
 	// (glyph, first pixel).
-	for (uint32_t g = tid; g < n_glyphs; g += kPlanThreads) {
-		const OutlineRect r = rects[g];
-		uint32_t cls, T, nspans, weight;
-		classify(r, cls, T, nspans, weight);
+	auto entries = [&](uint32_t g, const OutlineRect &r, uint32_t cls, uint32_t T, uint32_t nspans, uint32_t weight) {
 		if (!nspans)
-			continue;
+			return;
 		uint32_t at = atomicAdd(&s_hist[cls][plan_bucket(weight)], nspans);
 		const unsigned long long px = (unsigned long long)r.w * r.h;
 		for (unsigned long long p = 0; p < px; p += 256ull * T) {
 			const uint32_t left = (uint32_t)((px - p + 255ull) >> 8);
 			tiles[at++] = make_uint2(g, span_list && cls == 0 ? ((uint32_t)p | min(T, left)) : (uint32_t)p);
+		}
+	};
+	if (kept) {
+#pragma unroll
+		for (uint32_t j = 0; j < kKeep; j++)
+			if (g_lo + j < g_hi)
+				entries(g_lo + j, kr[j], kcls[j], kT[j], kn[j], kw[j]);
+	} else {
+		for (uint32_t g = tid; g < n_glyphs; g += kPlanThreads) {
+			const OutlineRect r = rects[g];
+			uint32_t cls, T, nspans, weight;
+			classify(r, cls, T, nspans, weight);
+			entries(g, r, cls, T, nspans, weight);
 		}
 	}
 }
