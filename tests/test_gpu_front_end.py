@@ -166,6 +166,37 @@ def test_packed_upload_form_equals_the_record_form(vg, fira_oracle):
     c.close()
 
 
+def test_one_submission_with_a_glyph_for_the_brute_force_class(oracle, vg):
+    """a bitmap too wide for the span kernel's winding histogram goes to the brute-force kernel: the raster enqueued
+    behind the plan must not run (PlanHeader::ok = 0) and the second launches must give the oracle's bytes"""
+    M, L, Z = 0, 1, 4
+    wide = [(0, 0, 0, 0, 0, 0, M), (0, 0, 0, 0, 60000, 0, L), (0, 0, 0, 0, 60000, 1000, L), (0, 0, 0, 0, 0, 1000, L), (0,) * 6 + (Z,)]
+    small = [(0, 0, 0, 0, 100, 100, M), (0, 0, 0, 0, 900, 100, L), (0, 0, 0, 0, 500, 800, L), (0,) * 6 + (Z,)]
+    cmds = np.array(small + wide + small, dtype=vg.OUTLINE_CMD_DTYPE)
+    cmd_off = np.array([0, 4, 9, 13], np.uint32)
+    scale = np.full(3, 24.0 / 1000.0)
+    shift = np.array([0.0, 0.25, -0.125])
+    c = vg.SdfContext(0)
+    for _ in range(2):
+        rects, out, ob, ns = c.outlines_render_into(cmd_off, cmds, scale, shift, 1 << 20)
+        assert out is not None and int(rects[1]["w"]) > 1400 and len(out) == ob
+        off = 0
+        for g, st in enumerate((small, wide, small)):
+            segs = []
+            for r in oracle.build_rings([(k[6],) + tuple(k[:6]) for k in st]):
+                p = r * scale[g]
+                p[:, 0] += shift[g]
+                p[:, 1] += 0.0
+                segs.append(np.concatenate([p[:-1], p[1:]], axis=1))
+            r = rects[g]
+            want = oracle.sdf_render(np.concatenate(segs), int(r["x0"]), int(r["y0"]), int(r["w"]), int(r["h"]))
+            n = want.size
+            assert np.array_equal(out[off:off + n].reshape(want.shape), want), g
+            off += n
+        assert off == ob
+    c.close()
+
+
 def test_arbitrary_command_streams(oracle, vg, ctx):
     # streams ttf-parser never emits: curve_to, quad_to on an empty ring, line_to starting a
     # ring, missing close, degenerate rings, repeated closes; rings via the oracle's RingBuilder
