@@ -12,7 +12,8 @@
 // (-ffp-contract=off, IEEE divide).
 //
 // Pipeline: five launches, no intermediate point arrays, one read-back (the rects) for the host:
-//   context  wave per glyph: is the ring non-empty in front of every command
+//   context  wave per glyph: is the ring non-empty in front of every command; commands that arrive in the compact
+//            upload form (kind byte + the coordinates the kind carries) are expanded into 28-byte records here
 //   count    wave per 64 commands: first flattening pass — how many points every command appends, their
 //            bounding box (nothing else is stored)
 //   rings    wave per glyph: point offsets inside the glyph, ring acceptance / closing rules, segment count,
