@@ -53,3 +53,55 @@ def test_product_library_holds_only_product_kernels(vg):
     lib.vgsdf_kernel_known.argtypes = [ctypes.c_int]
     known = [k for k in range(0, 100) if lib.vgsdf_kernel_known(k)]
     assert known == [1, 50]
+
+
+_C_PROGRAM = r"""
+/* the `recurse` flow of INTEGRATION.md section 5 from plain C (dummy renderer: runs without a GPU) */
+#include <stdio.h>
+#include "vgsdf.h"
+#include "vgfont.h"
+int main(int argc, char **argv)
+{
+	if (argc < 3)
+		return 2;
+	vg_manager *m = vg_manager_new(1);
+	if (!m || vg_manager_scan(m, argv[1]) < 0) {
+		fprintf(stderr, "scan: %s\n", vg_last_error());
+		return 1;
+	}
+	vg_renderer *r = vg_renderer_new(VG_MODE_DUMMY, 0);
+	vg_writer *w = vg_writer_new_dir(argv[2]);
+	if (!r || !w || vg_manager_render_glyphs_to(m, r, w) < 0 || vg_manager_write_index_json(m, w) < 0 ||
+	    vg_manager_write_families_json(m, w) < 0 || vg_writer_finish(w) < 0) {
+		fprintf(stderr, "render: %s\n", vg_last_error());
+		return 1;
+	}
+	vg_writer_free(w);
+	vg_renderer_free(r);
+	vg_manager_free(m);
+	printf("devices %d\n", vgsdf_device_count());
+	return 0;
+}
+"""
+
+
+def test_headers_are_plain_c_and_the_library_links_from_c(vg, tmp_path):
+    """include/*.h compile as C99 (-pedantic) and a C program linked against libvgsdf.so runs the scan -> render ->
+    index flow (the boundary a cgo / JNI / Rust FFI binding would use)"""
+    import shutil
+    import subprocess
+    from conftest import FIRA
+    src = tmp_path / "recurse.c"
+    src.write_text(_C_PROGRAM)
+    exe = tmp_path / "recurse"
+    lib = vg.lib_path()
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe),
+                    f"-L{lib.parent}", f"-l:{lib.name}", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    fonts = tmp_path / "fonts"
+    fonts.mkdir()
+    shutil.copy(FIRA, fonts / "Fira Sans - Regular.ttf")
+    out = tmp_path / "out"
+    p = subprocess.run([str(exe), str(fonts), str(out)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert (out / "index.json").exists() and (out / "font_families.json").exists()
+    assert len(list((out / "fira_sans_regular").glob("*.pbf"))) == 256
