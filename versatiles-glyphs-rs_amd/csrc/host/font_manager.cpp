@@ -830,7 +830,9 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 	size_t total_glyphs = 0;
 	for (const Todo &t : tasks)
 		total_glyphs += t.block.len();
-	constexpr size_t kFeGlyphBudget = 32768, kFeMinGroup = 3500;
+	constexpr size_t kFeGlyphBudget = 32768;
+	static const char *mg = std::getenv("VG_FE_MIN_GROUP"); // (measurement switch)
+	const size_t kFeMinGroup = mg ? (size_t)std::max(1, std::atoi(mg)) : 3500;
 	const size_t n_groups = std::max<size_t>(1, total_glyphs / kFeMinGroup);
 	const size_t budget = std::min(kFeGlyphBudget, (total_glyphs + n_groups - 1) / n_groups);
 	std::vector<std::pair<size_t, size_t>> groups;
