@@ -150,6 +150,44 @@ def test_every_operator_hints_widths_and_subroutines(vg, ops_cff):
     assert got[0x46] == []                               # "empty": no callbacks -> PbfGlyph::empty (renderer.rs:118-120)
 
 
+def test_seac_accented_glyphs(vg):
+    """`adx ady bchar achar endchar`: the base glyph and the accent (codes of the StandardEncoding, looked up through the
+    charset) drawn one after the other, the accent moved by (adx, ady) — against fontTools' decomposition"""
+    from fontTools.pens.recordingPen import DecomposingRecordingPen
+    names = [".notdef", "A", "acute", "Aacute", "dieresis", "Adieresis", "o", "oacute"]
+    progs = [
+        [0, "hmoveto", "endchar"],
+        [600, 100, 0, "rmoveto", 200, 700, "rlineto", 200, -700, "rlineto", "endchar"],
+        [300, 10, 20, "hstem", 50, 60, "rmoveto", 80, 120, "rlineto", -40, 0, "rlineto", "endchar"],
+        [640, 150, 700, 65, 194, "endchar"],          # width 640, A + acute at (150, 700)
+        [250, 0, "rmoveto", 60, "hlineto", 60, "vlineto", -60, "hlineto", 100, 0, "rmoveto", 60, "hlineto", 60, "vlineto", -60, "hlineto", "endchar"],
+        [100, 720, 65, 200, "endchar"],                # no width operand: A + dieresis
+        [550, 100, 100, "rmoveto", 100, 0, 100, 100, 0, 100, "rrcurveto", -100, 0, -100, -100, 0, -100, "rrcurveto", "endchar"],
+        [-20, 520, 111, 194, "endchar"],               # o + acute
+    ]
+    cs = {n: T2CharString(program=list(p)) for n, p in zip(names, progs)}
+    cmap = {0x41: "A", 0xB4: "acute", 0xC1: "Aacute", 0xA8: "dieresis", 0xC4: "Adieresis", 0x6F: "o", 0xF3: "oacute"}
+    font = _build(names, cmap, cs, {n: 600 for n in names})
+    f = TTFont(io.BytesIO(font))
+    gs = f.getGlyphSet()
+    got, _ = _product_callbacks(vg, font)
+    for cp, name in cmap.items():
+        rp = DecomposingRecordingPen(gs)
+        gs[name].draw(rp)
+        want = []
+        for op, a in rp.value:
+            if op == "moveTo":
+                want.append((M, 0, 0, 0, 0) + tuple(float(v) for v in a[0]))
+            elif op == "lineTo":
+                want.append((L, 0, 0, 0, 0) + tuple(float(v) for v in a[0]))
+            elif op == "curveTo":
+                want.append((C,) + tuple(float(v) for pt in a for v in pt))
+            elif op in ("closePath", "endPath"):
+                want.append((Z, 0, 0, 0, 0, 0, 0))
+        assert got[cp] == want, name
+    assert sum(1 for t in got[0xC1] if t[0] == M) == 2 and sum(1 for t in got[0xC4] if t[0] == M) == 3
+
+
 def test_cid_keyed_font(vg, ops_cff):
     """the same charstrings behind ROS / FDArray / FDSelect (local subroutines come from the glyph's font dict)"""
     from fontTools.cffLib import FDArrayIndex, FDSelect, FontDict

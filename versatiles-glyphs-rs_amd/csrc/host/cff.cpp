@@ -183,7 +183,10 @@ std::optional<CffTable> CffTable::parse(Bytes table)
 		if (op == -2)
 			return std::nullopt;
 		const auto &v = r.operands;
-		if (op == 17 && v.size() == 1) {
+		if (op == 15 && v.size() == 1) {
+			if (!to_offset(v[0], t.charset_at_))
+				return std::nullopt;
+		} else if (op == 17 && v.size() == 1) {
 			if (!to_offset(v[0], charstrings_at))
 				return std::nullopt;
 		} else if (op == 18 && v.size() == 2) {
@@ -256,27 +259,95 @@ const CffTable::Index *CffTable::local_subrs_for(uint16_t gid) const
 	return fd < fd_priv_.size() ? &fd_priv_[fd].local_subrs : nullptr;
 }
 
+// StandardEncoding code -> string id (Technical Note #5176, appendices A and B), then string id -> glyph through
+// the charset (section 13: format 0 = one SID per glyph, formats 1 / 2 = ranges with an 8- / 16-bit count).
+std::optional<uint16_t> CffTable::standard_code_to_glyph(uint32_t code) const
+{
+	uint32_t sid = 0;
+	if (code >= 32 && code <= 126)
+		sid = code - 31;
+	else if (code >= 161 && code <= 175)
+		sid = code - 65;
+	else if (code >= 177 && code <= 180)
+		sid = code - 66;
+	else if (code >= 182 && code <= 189)
+		sid = code - 67;
+	else if (code == 191)
+		sid = 123;
+	else if (code >= 193 && code <= 200)
+		sid = code - 69;
+	else if (code >= 202 && code <= 203)
+		sid = code - 70;
+	else if (code >= 205 && code <= 208)
+		sid = code - 71;
+	else {
+		static const uint16_t rest[][2] = {{225, 138}, {227, 139}, {232, 140}, {233, 141}, {234, 142}, {235, 143},
+		                                   {241, 144}, {245, 145}, {248, 146}, {249, 147}, {250, 148}, {251, 149}};
+		for (const auto &r : rest)
+			if (r[0] == code)
+				sid = r[1];
+	}
+	if (sid == 0 || cid_)
+		return std::nullopt;
+	const uint32_t n = charstrings_.count;
+	if (charset_at_ == 0) // ISOAdobe: glyph id = string id
+		return sid <= 228 && sid < n ? std::optional<uint16_t>((uint16_t)sid) : std::nullopt;
+	if (charset_at_ <= 2) // the Expert charsets hold none of these glyphs under their standard names (as ttf-parser: none)
+		return std::nullopt;
+	const Bytes c = table_.from(charset_at_);
+	if (!c.has(0, 1))
+		return std::nullopt;
+	const uint8_t format = c.u8(0);
+	if (format == 0) {
+		for (uint32_t g = 1; g < n; g++) {
+			if (!c.has(1 + 2 * (size_t)(g - 1), 2))
+				break;
+			if (c.u16(1 + 2 * (size_t)(g - 1)) == sid)
+				return (uint16_t)g;
+		}
+		return std::nullopt;
+	}
+	if (format != 1 && format != 2)
+		return std::nullopt;
+	const size_t rec = format == 1 ? 3 : 4;
+	uint32_t g = 1;
+	for (size_t at = 1; g < n; at += rec) {
+		if (!c.has(at, rec))
+			break;
+		const uint32_t first = c.u16(at), left = format == 1 ? c.u8(at + 2) : c.u16(at + 2);
+		if (sid >= first && sid <= first + left) {
+			const uint32_t hit = g + (sid - first);
+			return hit < n ? std::optional<uint16_t>((uint16_t)hit) : std::nullopt;
+		}
+		g += left + 1;
+	}
+	return std::nullopt;
+}
+
+// bbox of everything handed to the builder (control points included), as ttf-parser's Builder keeps it
+struct CffBounds {
+	float x0 = std::numeric_limits<float>::max(), y0 = std::numeric_limits<float>::max();
+	float x1 = std::numeric_limits<float>::lowest(), y1 = std::numeric_limits<float>::lowest();
+};
+
 // One glyph's charstring program (Technical Note #5177).
 struct CharStringRun {
-	CharStringRun(const CffTable &table, OutlineBuilder &builder) : t(table), out(builder) {}
+	CharStringRun(const CffTable &table, OutlineBuilder &builder, CffBounds &bounds) : t(table), out(builder), bb(bounds) {}
 	const CffTable &t;
 	OutlineBuilder &out;
+	CffBounds &bb;
 	const CffTable::Index *local = nullptr;
 	float stack[kMaxOperands];
 	int sp = 0;
 	float x = 0.0f, y = 0.0f;
 	bool has_move_to = false, first_move_to = true, have_width = false, has_endchar = false;
 	uint32_t stems = 0;
-	// bbox of everything handed to the builder (control points included), as ttf-parser's Builder keeps it
-	float bx0 = std::numeric_limits<float>::max(), by0 = std::numeric_limits<float>::max();
-	float bx1 = std::numeric_limits<float>::lowest(), by1 = std::numeric_limits<float>::lowest();
-
 	void extend(float px, float py)
 	{
-		bx0 = px < bx0 ? px : bx0;
-		by0 = py < by0 ? py : by0;
-		bx1 = px > bx1 ? px : bx1;
-		by1 = py > by1 ? py : by1;
+		bb.x0 = px < bb.x0 ? px : bb.x0;
+		bb.y0 = py < bb.y0 ? py : bb.y0;
+		bb.x1 = px > bb.x1 ? px : bb.x1;
+		bb.y1 = py > bb.y1 ? py : bb.y1;
 	}
 	void move_to(float px, float py)
 	{
@@ -602,8 +673,42 @@ struct CharStringRun {
 			case 11: // return
 				return true;
 			case 14: // endchar
-				if (sp == 4 || (!have_width && sp == 5))
-					return false; // seac form (accented character from two glyphs of the standard encoding): not handled
+				if (sp == 4 || (!have_width && sp == 5)) {
+					// seac form: adx ady bchar achar — the base glyph, then the accent moved by (adx, ady), each a
+					// charstring of its own (path, hints and width operand start afresh)
+					const int a = sp - 4;
+					const float adx = stack[a], ady = stack[a + 1], bchar = stack[a + 2], achar = stack[a + 3];
+					have_width = true;
+					sp = 0;
+					if (depth == kMaxDepth)
+						return false;
+					if (!first_move_to) { // (a path of the accented glyph itself ends here)
+						first_move_to = true;
+						out.close();
+					}
+					if (!(bchar >= 0.0f && bchar <= 255.0f && achar >= 0.0f && achar <= 255.0f))
+						return false;
+					const auto bg = t.standard_code_to_glyph((uint32_t)bchar), ag = t.standard_code_to_glyph((uint32_t)achar);
+					if (!bg || !ag)
+						return false;
+					const float origin[2][2] = {{0.0f, 0.0f}, {adx, ady}};
+					const uint16_t part[2] = {*bg, *ag};
+					for (int k = 0; k < 2; k++) {
+						const auto pcs = t.charstrings_.get(part[k]);
+						if (!pcs)
+							return false;
+						CharStringRun sub(t, out, bb);
+						sub.local = local;
+						sub.x = origin[k][0];
+						sub.y = origin[k][1];
+						if (!sub.run(*pcs, depth + 1) || !sub.has_endchar)
+							return false;
+					}
+					if (pos != cs.size())
+						return false; // data after endchar
+					has_endchar = true;
+					return true;
+				}
 				if (sp == 1 && !have_width)
 					have_width = true;
 				sp = 0;
@@ -688,15 +793,16 @@ bool CffTable::outline(uint16_t gid, OutlineBuilder &builder) const
 	const auto cs = charstrings_.get(gid);
 	if (!cs)
 		return false;
-	CharStringRun r(*this, builder);
+	CffBounds bb;
+	CharStringRun r(*this, builder, bb);
 	r.local = local_subrs_for(gid);
 	if (!r.run(*cs, 0) || !r.has_endchar)
 		return false;
 	// ttf-parser: a glyph that produced no point has no outline (ZeroBBox); neither has one whose bbox leaves i16
-	if (r.bx0 == std::numeric_limits<float>::max())
+	if (bb.x0 == std::numeric_limits<float>::max())
 		return false;
 	auto fits = [](float v) { return v >= -32768.0f && v <= 32767.0f; };
-	return fits(r.bx0) && fits(r.by0) && fits(r.bx1) && fits(r.by1);
+	return fits(bb.x0) && fits(bb.y0) && fits(bb.x1) && fits(bb.y1);
 }
 
 } // namespace vg

@@ -8,8 +8,10 @@
 // subroutine calls, a glyph without any point yields no outline.
 // No fixture of the reference holds CFF outlines: parity with the crate is UNPINNED here; the reader is
 // checked against fontTools' charstring interpreter instead (tests/test_cff_outlines.py).
-// Not handled (-> no outline for that glyph): `endchar` in its seac form, the arithmetic / storage operators
-// of ESC (ttf-parser rejects them too), CFF2.
+// `endchar` in its seac form (an accented character assembled from two glyphs of the standard encoding) draws the
+// base glyph and then the accent at (adx, ady), each as a charstring of its own, through the font's charset.
+// Not handled (-> no outline for that glyph): the arithmetic / storage operators of ESC (ttf-parser rejects them
+// too), seac in CID-keyed fonts or with the Expert charsets, CFF2.
 #pragma once
 #include <cstdint>
 #include <optional>
@@ -40,6 +42,8 @@ private:
 	};
 	static bool parse_private(Bytes table, size_t offset, size_t size, PrivateDict &out);
 	const Index *local_subrs_for(uint16_t glyph_id) const;
+	// glyph of a code of Adobe's StandardEncoding (seac operands), through the charset; nullopt: none
+	std::optional<uint16_t> standard_code_to_glyph(uint32_t code) const;
 
 	Bytes table_;
 	Index global_subrs_, charstrings_;
@@ -47,6 +51,7 @@ private:
 	PrivateDict private_;              // name-keyed fonts
 	std::vector<PrivateDict> fd_priv_; // CID-keyed fonts: one per font dict
 	Bytes fd_select_;                  // CID-keyed fonts: FDSelect, from its format byte
+	size_t charset_at_ = 0;            // Top DICT `charset`: 0 / 1 / 2 = ISOAdobe / Expert / ExpertSubset, else its offset
 
 	friend struct CharStringRun;
 };
