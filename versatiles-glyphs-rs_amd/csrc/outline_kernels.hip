@@ -901,14 +901,19 @@ __device__ __forceinline__ unsigned long long block_exclusive_sum(unsigned long 
 	if (lane == 63)
 		s_wave[wv] = incl;
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		unsigned long long acc = 0;
-		for (int w = 0; w < kPlanThreads / 64; w++) {
-			const unsigned long long t = s_wave[w];
-			s_wave[w] = acc;
-			acc += t;
+	if (wv == 0) { // the 16 wave totals: one shuffle scan in the first wave
+		constexpr int kWaves = kPlanThreads / 64;
+		const unsigned long long t = lane < (uint32_t)kWaves ? s_wave[lane] : 0ull;
+		unsigned long long in = t;
+		for (int d = 1; d < kWaves; d <<= 1) {
+			const unsigned long long o = __shfl_up(in, d);
+			if ((int)lane >= d)
+				in += o;
 		}
-		s_wave[kPlanThreads / 64] = acc;
+		if (lane < (uint32_t)kWaves)
+			s_wave[lane] = in - t;
+		if (lane == (uint32_t)kWaves - 1)
+			s_wave[kWaves] = in;
 	}
 	__syncthreads();
 	total = s_wave[kPlanThreads / 64];
