@@ -964,9 +964,9 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	bool bad = false;
 	const uint32_t per = (n_glyphs + kPlanThreads - 1) / kPlanThreads;
 	const uint32_t g_lo = min(tid * per, n_glyphs), g_hi = min(g_lo + per, n_glyphs);
-	// a run of up to four glyphs (batches of <= 4096 glyphs: a font) stays in registers with its classification, so
+	// a run of up to eight glyphs (batches of <= 8192 glyphs: every group the dispatcher forms) stays in registers with its classification, so
 	// the rects are read once and classified once for both passes
-	constexpr uint32_t kKeep = 4;
+	constexpr uint32_t kKeep = 8;
 	const bool kept = per <= kKeep;
 	OutlineRect kr[kKeep];
 	uint32_t kcls[kKeep], kT[kKeep], kn[kKeep], kw[kKeep];
