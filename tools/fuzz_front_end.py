@@ -1,7 +1,11 @@
 """Differential fuzzing of the device front-end (outline commands -> flattened, closed, scaled
 segments + rects) against the oracle's RingBuilder restatement: random command streams, including
 ones ttf-parser never emits (curves on an empty ring, missing / repeated closes, cubic segments,
-degenerate and repeated points, tiny and huge coordinates).  Exits non-zero at the first difference."""
+degenerate and repeated points, tiny and huge coordinates).  Exits non-zero at the first difference.
+
+    python tools/fuzz_front_end.py seconds seed [curves]
+`curves`: outline-like streams of mostly cubics and quadratics whose control points stay near the chord (the depths the
+parallel flattening rounds take: 0..6), also with coordinates at the flatness threshold."""
 import sys
 import time
 from pathlib import Path
@@ -17,6 +21,7 @@ vg = load_product()
 budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
+curvy = len(sys.argv) > 3 and sys.argv[3] == "curves"
 ctx = vg.SdfContext(0)
 M, L, Q, C, Z = 0, 1, 2, 3, 4
 
@@ -25,7 +30,40 @@ def f32(v):
     return float(np.float32(v))
 
 
+def curvy_stream():
+    """closed contours of chained curves: end points on a rough circle, control points within a fraction of the chord"""
+    cmds = []
+    upem = float(rng.choice([256, 1000, 2048]))
+    for _ in range(int(rng.integers(1, 5))):
+        cx, cy = rng.uniform(0, upem, 2)
+        rad = rng.uniform(0.02, 0.5) * upem
+        k = int(rng.integers(3, 24))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        pts = [(f32(cx + rad * np.cos(a) * rng.uniform(0.7, 1.3)), f32(cy + rad * np.sin(a) * rng.uniform(0.7, 1.3))) for a in ang]
+        cmds.append((M, 0, 0, 0, 0, pts[0][0], pts[0][1]))
+        last = pts[0]
+        for p in pts[1:] + [pts[0]]:
+            kind = rng.choice([L, Q, C], p=[.15, .35, .5])
+            ch = (p[0] - last[0], p[1] - last[1])
+            bulge = rng.choice([0.0, 0.02, 0.2, 0.6]) * float(np.hypot(*ch))
+            def ctl(t):
+                return (f32(last[0] + t * ch[0] + rng.normal(0, 1) * bulge), f32(last[1] + t * ch[1] + rng.normal(0, 1) * bulge))
+            if kind == L:
+                cmds.append((L, 0, 0, 0, 0, p[0], p[1]))
+            elif kind == Q:
+                c1 = ctl(0.5)
+                cmds.append((Q, c1[0], c1[1], 0, 0, p[0], p[1]))
+            else:
+                c1, c2 = ctl(0.33), ctl(0.67)
+                cmds.append((C, c1[0], c1[1], c2[0], c2[1], p[0], p[1]))
+            last = p
+        cmds.append((Z, 0, 0, 0, 0, 0, 0))
+    return cmds, 24.0 / upem, float(rng.uniform(-0.5, 0.5))
+
+
 def stream():
+    if curvy:
+        return curvy_stream()
     n = int(rng.choice([0, 1, 3, 8, 30, 120]))
     span = float(rng.choice([50, 1000, 2048, 16000]))
     snap = rng.choice([0, 0, 1, 4])
