@@ -48,8 +48,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(str(LIB_PATH))
+        # VG_ORACLE_LIB: another build of the oracle (tools/run_asan.sh loads the sanitizer build)
+        other = os.environ.get("VG_ORACLE_LIB")
+        if not other:
+            build()
+        L = C.CDLL(other or str(LIB_PATH))
         vp, u8p, u32p, i32p, f64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), \
             C.POINTER(C.c_int32), C.POINTER(C.c_double)
         L.vgo_font_open.restype = vp

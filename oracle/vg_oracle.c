@@ -40,7 +40,7 @@ typedef struct {
 struct vgo_font {
 	uint8_t *data;
 	size_t len;
-	span head, maxp, hhea, hmtx, loca, glyf, cmap;
+	span head, maxp, hhea, hmtx, loca, glyf, cmap, cff;
 	int units_per_em, num_glyphs, num_hmetrics, loca_long;
 	size_t loca_count;
 };
@@ -81,6 +81,7 @@ vgo_font *vgo_font_open(const uint8_t *data, size_t len)
 	f->loca = find_table(f->data, len, "loca");
 	f->glyf = find_table(f->data, len, "glyf");
 	f->cmap = find_table(f->data, len, "cmap");
+	f->cff = find_table(f->data, len, "CFF ");
 	if (!f->head.p || f->head.len < 54 || !f->maxp.p || f->maxp.len < 6 || !f->hhea.p ||
 	    f->hhea.len < 36) {
 		vgo_font_close(f);
@@ -754,10 +755,730 @@ static int outline_impl(const vgo_font *f, span g, int depth, cmd_sink *sink, xf
 	return 1;
 }
 
+/* ------------------------------------------------------------------------------------
+ * `CFF ` (version 1) outline emission — what ttf-parser's cff1 table does behind
+ * Face::outline_glyph (call site renderer.rs:110) for OpenType fonts with Type 2 charstrings.
+ * Restated from Adobe Technical Notes #5176 (CFF) and #5177 (Type 2 charstrings) and the crate's
+ * observable rules: callbacks in f32, one f32 addition per coordinate in operand order, close()
+ * before every further move_to and at endchar, the width operand taken once, at most 48 operands
+ * and 10 nested calls, no outline for a glyph without points or with a bbox beyond i16.
+ * PARITY UNPINNED: no fixture of the reference holds a CFF font; tests compare this reader, the
+ * product's reader and fontTools on fonts synthesised with fontTools.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	span tab;        /* the whole table */
+	uint32_t count;  /* objects */
+	int off_size;
+	size_t offs, base; /* position of the offset array / of the byte before the object data */
+} cff_index;
+
+static uint32_t cff_off(const cff_index *ix, uint32_t i)
+{
+	uint32_t v = 0;
+	for (int k = 0; k < ix->off_size; k++)
+		v = (v << 8) | ix->tab.p[ix->offs + (size_t)i * ix->off_size + k];
+	return v;
+}
+
+/* parses the INDEX at `at`; returns the position behind it, 0 on malformed data */
+static size_t cff_index_at(span t, size_t at, cff_index *ix)
+{
+	memset(ix, 0, sizeof *ix);
+	ix->tab = t;
+	if (!rd_ok(t.len, at, 2))
+		return 0;
+	ix->count = be16(t.p + at);
+	if (ix->count == 0)
+		return at + 2;
+	if (!rd_ok(t.len, at, 3))
+		return 0;
+	ix->off_size = t.p[at + 2];
+	if (ix->off_size < 1 || ix->off_size > 4)
+		return 0;
+	ix->offs = at + 3;
+	size_t n_off = ((size_t)ix->count + 1) * ix->off_size;
+	if (!rd_ok(t.len, ix->offs, n_off))
+		return 0;
+	ix->base = ix->offs + n_off - 1;
+	uint32_t last = cff_off(ix, ix->count);
+	if (last < 1 || !rd_ok(t.len, ix->base + 1, (size_t)last - 1))
+		return 0;
+	return ix->base + last;
+}
+
+static int cff_get(const cff_index *ix, uint32_t i, span *out)
+{
+	if (i >= ix->count)
+		return 0;
+	uint32_t a = cff_off(ix, i), b = cff_off(ix, i + 1);
+	if (a < 1 || b < a || !rd_ok(ix->tab.len, ix->base + a, b - a))
+		return 0;
+	out->p = ix->tab.p + ix->base + a;
+	out->len = b - a;
+	return 1;
+}
+
+/* DICT walk: calls back with (operator, operands); two-byte operators are 1200 + second byte */
+typedef struct {
+	double v[48];
+	int n;
+} cff_operands;
+typedef void (*cff_dict_fn)(int op, const cff_operands *a, void *ctx);
+
+static int cff_dict(span d, cff_dict_fn fn, void *ctx)
+{
+	cff_operands a;
+	a.n = 0;
+	size_t p = 0;
+	while (p < d.len) {
+		uint8_t b = d.p[p];
+		if (b <= 21) {
+			int op = b;
+			p++;
+			if (b == 12) {
+				if (p >= d.len)
+					return 0;
+				op = 1200 + d.p[p++];
+			}
+			fn(op, &a, ctx);
+			a.n = 0;
+			continue;
+		}
+		double v = 0;
+		if (b == 28) {
+			if (!rd_ok(d.len, p, 3))
+				return 0;
+			v = (int16_t)be16(d.p + p + 1);
+			p += 3;
+		} else if (b == 29) {
+			if (!rd_ok(d.len, p, 5))
+				return 0;
+			v = (int32_t)be32(d.p + p + 1);
+			p += 5;
+		} else if (b == 30) { /* real: skipped nibble by nibble */
+			p++;
+			for (;;) {
+				if (p >= d.len)
+					return 0;
+				uint8_t q = d.p[p++];
+				if ((q >> 4) == 0xF || (q & 0xF) == 0xF)
+					break;
+			}
+		} else if (b >= 32 && b <= 246) {
+			v = (int)b - 139;
+			p++;
+		} else if (b >= 247 && b <= 250) {
+			if (!rd_ok(d.len, p, 2))
+				return 0;
+			v = ((int)b - 247) * 256 + d.p[p + 1] + 108;
+			p += 2;
+		} else if (b >= 251 && b <= 254) {
+			if (!rd_ok(d.len, p, 2))
+				return 0;
+			v = -((int)b - 251) * 256 - d.p[p + 1] - 108;
+			p += 2;
+		} else {
+			return 0;
+		}
+		if (a.n < 48)
+			a.v[a.n++] = v;
+	}
+	return 1;
+}
+
+typedef struct {
+	span tab;
+	cff_index gsubrs, chars, fd_array;
+	cff_index lsubrs;            /* name-keyed fonts */
+	int have_lsubrs, is_cid;
+	size_t charset, fd_select;
+	size_t priv_size, priv_at;
+	int have_priv, bad;
+	size_t chars_at, fd_array_at;
+} cff_font;
+
+static void cff_top_op(int op, const cff_operands *a, void *vctx)
+{
+	cff_font *c = (cff_font *)vctx;
+	double last = a->n ? a->v[a->n - 1] : 0;
+	if (op == 15 && a->n == 1)
+		c->charset = (size_t)last;
+	else if (op == 17 && a->n == 1)
+		c->chars_at = (size_t)last;
+	else if (op == 18 && a->n == 2) {
+		c->priv_size = (size_t)a->v[0];
+		c->priv_at = (size_t)a->v[1];
+		c->have_priv = 1;
+	} else if (op == 1206 && a->n == 1 && last != 2.0)
+		c->bad = 1;
+	else if (op == 1230)
+		c->is_cid = 1;
+	else if (op == 1236 && a->n == 1)
+		c->fd_array_at = (size_t)last;
+	else if (op == 1237 && a->n == 1)
+		c->fd_select = (size_t)last;
+}
+
+typedef struct {
+	size_t subrs_rel;
+	int have;
+} cff_priv_ctx;
+
+static void cff_priv_op(int op, const cff_operands *a, void *vctx)
+{
+	cff_priv_ctx *p = (cff_priv_ctx *)vctx;
+	if (op == 19 && a->n == 1) {
+		p->subrs_rel = (size_t)a->v[0];
+		p->have = 1;
+	}
+}
+
+/* local subroutines of a Private DICT at (at, size); 1 if an INDEX was found */
+static int cff_local_subrs(span t, size_t at, size_t size, cff_index *out)
+{
+	if (!rd_ok(t.len, at, size))
+		return 0;
+	span d = {t.p + at, size};
+	cff_priv_ctx pc = {0, 0};
+	if (!cff_dict(d, cff_priv_op, &pc) || !pc.have)
+		return 0;
+	return cff_index_at(t, at + pc.subrs_rel, out) != 0;
+}
+
+static int cff_open(span t, cff_font *c)
+{
+	memset(c, 0, sizeof *c);
+	c->tab = t;
+	if (t.len < 4 || t.p[0] != 1)
+		return 0;
+	size_t p = t.p[2];
+	cff_index names, tops, strings;
+	if (!(p = cff_index_at(t, p, &names)) || !(p = cff_index_at(t, p, &tops)) || !(p = cff_index_at(t, p, &strings)) ||
+	    !(p = cff_index_at(t, p, &c->gsubrs)))
+		return 0;
+	span top;
+	if (!cff_get(&tops, 0, &top) || !cff_dict(top, cff_top_op, c) || c->bad)
+		return 0;
+	if (!c->chars_at || !cff_index_at(t, c->chars_at, &c->chars) || c->chars.count == 0)
+		return 0;
+	if (c->is_cid) {
+		if (!c->fd_array_at || !c->fd_select || !cff_index_at(t, c->fd_array_at, &c->fd_array) || !rd_ok(t.len, c->fd_select, 1))
+			return 0;
+	} else if (c->have_priv) {
+		c->have_lsubrs = cff_local_subrs(t, c->priv_at, c->priv_size, &c->lsubrs);
+	}
+	return 1;
+}
+
+typedef struct {
+	size_t size, at;
+	int have;
+} cff_fd_ctx;
+
+static void cff_fd_op(int op, const cff_operands *a, void *vctx)
+{
+	cff_fd_ctx *f = (cff_fd_ctx *)vctx;
+	if (op == 18 && a->n == 2) {
+		f->size = (size_t)a->v[0];
+		f->at = (size_t)a->v[1];
+		f->have = 1;
+	}
+}
+
+/* local subroutines that apply to glyph gid; 0: none */
+static int cff_glyph_lsubrs(const cff_font *c, int gid, cff_index *out)
+{
+	if (!c->is_cid) {
+		*out = c->lsubrs;
+		return c->have_lsubrs;
+	}
+	const uint8_t *s = c->tab.p + c->fd_select;
+	size_t left = c->tab.len - c->fd_select;
+	int fd = -1;
+	if (s[0] == 0) {
+		if (rd_ok(left, 1 + (size_t)gid, 1))
+			fd = s[1 + gid];
+	} else if (s[0] == 3 && left >= 3) {
+		int n = be16(s + 1);
+		for (int i = 0; i < n; i++) {
+			size_t r = 3 + (size_t)i * 3;
+			if (!rd_ok(left, r, 5))
+				break;
+			if (gid >= be16(s + r) && gid < be16(s + r + 3)) {
+				fd = s[r + 2];
+				break;
+			}
+		}
+	}
+	span dict;
+	if (fd < 0 || !cff_get(&c->fd_array, (uint32_t)fd, &dict))
+		return 0;
+	cff_fd_ctx fc = {0, 0, 0};
+	if (!cff_dict(dict, cff_fd_op, &fc) || !fc.have)
+		return 0;
+	return cff_local_subrs(c->tab, fc.at, fc.size, out);
+}
+
+/* StandardEncoding code -> SID -> glyph (seac); -1: none */
+static int cff_std_glyph(const cff_font *c, int code)
+{
+	static const uint8_t lo[] = {32, 161, 177, 182, 191, 193, 202, 205}, hi[] = {126, 175, 180, 189, 191, 200, 203, 208};
+	static const uint8_t sub[] = {31, 65, 66, 67, 68, 69, 70, 71};
+	static const uint8_t single[][2] = {{225, 138}, {227, 139}, {232, 140}, {233, 141}, {234, 142}, {235, 143},
+	                                    {241, 144}, {245, 145}, {248, 146}, {249, 147}, {250, 148}, {251, 149}};
+	int sid = 0;
+	for (size_t i = 0; i < sizeof lo; i++)
+		if (code >= lo[i] && code <= hi[i])
+			sid = code - sub[i];
+	for (size_t i = 0; i < sizeof single / 2; i++)
+		if (code == single[i][0])
+			sid = single[i][1];
+	if (!sid || c->is_cid)
+		return -1;
+	int n = (int)c->chars.count;
+	if (c->charset == 0)
+		return sid <= 228 && sid < n ? sid : -1;
+	if (c->charset <= 2 || !rd_ok(c->tab.len, c->charset, 1))
+		return -1;
+	const uint8_t *s = c->tab.p + c->charset;
+	size_t left = c->tab.len - c->charset;
+	if (s[0] == 0) {
+		for (int g = 1; g < n; g++) {
+			if (!rd_ok(left, 1 + 2 * (size_t)(g - 1), 2))
+				return -1;
+			if (be16(s + 1 + 2 * (g - 1)) == sid)
+				return g;
+		}
+		return -1;
+	}
+	if (s[0] != 1 && s[0] != 2)
+		return -1;
+	size_t rec = s[0] == 1 ? 3 : 4;
+	int g = 1;
+	for (size_t at = 1; g < n; at += rec) {
+		if (!rd_ok(left, at, rec))
+			return -1;
+		int first = be16(s + at), cnt = s[0] == 1 ? s[at + 2] : be16(s + at + 2);
+		if (sid >= first && sid <= first + cnt)
+			return g + (sid - first) < n ? g + (sid - first) : -1;
+		g += cnt + 1;
+	}
+	return -1;
+}
+
+typedef struct {
+	const cff_font *font;
+	cmd_sink *sink;
+	cff_index lsubrs;
+	int have_lsubrs;
+	float st[48];
+	int sp;
+	float x, y;
+	int moved, path_open, width_seen, ended;
+	uint32_t stems;
+	float bx0, by0, bx1, by1;
+	int any_point;
+} cff_run;
+
+static void cff_emit(cff_run *r, int kind, float x1, float y1, float x2, float y2, float x, float y)
+{
+	cmd_sink *k = r->sink;
+	if (k->n < k->cap) {
+		vgo_cmd *c = &k->out[k->n];
+		c->kind = kind;
+		c->x1 = x1, c->y1 = y1, c->x2 = x2, c->y2 = y2, c->x = x, c->y = y;
+	}
+	k->n++;
+}
+
+static void cff_bb(cff_run *r, float x, float y)
+{
+	if (!r->any_point) {
+		r->bx0 = r->bx1 = x;
+		r->by0 = r->by1 = y;
+		r->any_point = 1;
+		return;
+	}
+	if (x < r->bx0) r->bx0 = x;
+	if (x > r->bx1) r->bx1 = x;
+	if (y < r->by0) r->by0 = y;
+	if (y > r->by1) r->by1 = y;
+}
+
+static void cff_line(cff_run *r)
+{
+	cff_bb(r, r->x, r->y);
+	cff_emit(r, VGO_LINE, 0, 0, 0, 0, r->x, r->y);
+}
+
+static void cff_curve(cff_run *r, float x1, float y1, float x2, float y2)
+{
+	cff_bb(r, x1, y1);
+	cff_bb(r, x2, y2);
+	cff_bb(r, r->x, r->y);
+	cff_emit(r, VGO_CURVE, x1, y1, x2, y2, r->x, r->y);
+}
+
+/* six operands from a[0..5]: relative curve */
+static void cff_rcurve(cff_run *r, const float *a)
+{
+	float x1 = r->x + a[0], y1 = r->y + a[1];
+	float x2 = x1 + a[2], y2 = y1 + a[3];
+	r->x = x2 + a[4];
+	r->y = y2 + a[5];
+	cff_curve(r, x1, y1, x2, y2);
+}
+
+static int cff_moveto(cff_run *r, int skip, int use_x, int use_y)
+{
+	if (r->sp != skip + use_x + use_y)
+		return 0;
+	if (r->path_open)
+		cff_emit(r, VGO_CLOSE, 0, 0, 0, 0, 0, 0);
+	r->path_open = 1;
+	r->moved = 1;
+	int i = skip;
+	if (use_x)
+		r->x += r->st[i++];
+	if (use_y)
+		r->y += r->st[i++];
+	cff_bb(r, r->x, r->y);
+	cff_emit(r, VGO_MOVE, 0, 0, 0, 0, r->x, r->y);
+	r->sp = 0;
+	return 1;
+}
+
+static int cff_exec(cff_run *r, span cs, int depth);
+
+static int cff_component(cff_run *parent, int gid, float ox, float oy, int depth)
+{
+	span cs;
+	if (gid < 0 || !cff_get(&parent->font->chars, (uint32_t)gid, &cs))
+		return 0;
+	cff_run sub;
+	memset(&sub, 0, sizeof sub);
+	sub.font = parent->font;
+	sub.sink = parent->sink;
+	sub.lsubrs = parent->lsubrs;
+	sub.have_lsubrs = parent->have_lsubrs;
+	sub.x = ox;
+	sub.y = oy;
+	sub.any_point = parent->any_point;
+	sub.bx0 = parent->bx0, sub.by0 = parent->by0, sub.bx1 = parent->bx1, sub.by1 = parent->by1;
+	if (!cff_exec(&sub, cs, depth + 1) || !sub.ended)
+		return 0;
+	parent->any_point = sub.any_point;
+	parent->bx0 = sub.bx0, parent->by0 = sub.by0, parent->bx1 = sub.bx1, parent->by1 = sub.by1;
+	return 1;
+}
+
+static int cff_exec(cff_run *r, span cs, int depth)
+{
+	size_t p = 0;
+	while (p < cs.len) {
+		uint8_t op = cs.p[p++];
+		if (op == 28 || op >= 32) {
+			float v;
+			if (op == 28) {
+				if (!rd_ok(cs.len, p, 2))
+					return 0;
+				v = (float)(int16_t)be16(cs.p + p);
+				p += 2;
+			} else if (op <= 246) {
+				v = (float)((int)op - 139);
+			} else if (op <= 250) {
+				if (!rd_ok(cs.len, p, 1))
+					return 0;
+				v = (float)(((int)op - 247) * 256 + cs.p[p++] + 108);
+			} else if (op <= 254) {
+				if (!rd_ok(cs.len, p, 1))
+					return 0;
+				v = (float)(-((int)op - 251) * 256 - cs.p[p++] - 108);
+			} else {
+				if (!rd_ok(cs.len, p, 4))
+					return 0;
+				v = (float)(int32_t)be32(cs.p + p) / 65536.0f;
+				p += 4;
+			}
+			if (r->sp >= 48)
+				return 0;
+			r->st[r->sp++] = v;
+			continue;
+		}
+		float *s = r->st;
+		int n = r->sp;
+		switch (op) {
+		case 1: case 3: case 18: case 23: /* stems */
+			if ((n & 1) && !r->width_seen) {
+				r->width_seen = 1;
+				n--;
+			}
+			r->stems += (uint32_t)n >> 1;
+			r->sp = 0;
+			break;
+		case 19: case 20: /* hintmask, cntrmask */
+			r->sp = 0;
+			if (n & 1) {
+				n--;
+				r->width_seen = 1;
+			}
+			r->stems += (uint32_t)n >> 1;
+			p += (r->stems + 7) >> 3;
+			if (p > cs.len)
+				return 0;
+			break;
+		case 21: { /* rmoveto */
+			int skip = n == 3;
+			if (skip)
+				r->width_seen = 1;
+			if (!cff_moveto(r, skip, 1, 1))
+				return 0;
+			break;
+		}
+		case 22: { /* hmoveto */
+			int skip = n == 2;
+			if (skip)
+				r->width_seen = 1;
+			if (!cff_moveto(r, skip, 1, 0))
+				return 0;
+			break;
+		}
+		case 4: { /* vmoveto */
+			int skip = n == 2;
+			if (skip)
+				r->width_seen = 1;
+			if (!cff_moveto(r, skip, 0, 1))
+				return 0;
+			break;
+		}
+		case 5: /* rlineto */
+			if (!r->moved || (n & 1))
+				return 0;
+			for (int i = 0; i < n; i += 2) {
+				r->x += s[i];
+				r->y += s[i + 1];
+				cff_line(r);
+			}
+			r->sp = 0;
+			break;
+		case 6: case 7: { /* hlineto, vlineto: alternating */
+			if (!r->moved || n == 0)
+				return 0;
+			int horizontal = op == 6;
+			for (int i = 0; i < n; i++, horizontal = !horizontal) {
+				if (horizontal)
+					r->x += s[i];
+				else
+					r->y += s[i];
+				cff_line(r);
+			}
+			r->sp = 0;
+			break;
+		}
+		case 8: /* rrcurveto */
+			if (!r->moved || n % 6)
+				return 0;
+			for (int i = 0; i < n; i += 6)
+				cff_rcurve(r, s + i);
+			r->sp = 0;
+			break;
+		case 24: { /* rcurveline */
+			if (!r->moved || n < 8 || (n - 2) % 6)
+				return 0;
+			int i = 0;
+			for (; i + 6 <= n - 2; i += 6)
+				cff_rcurve(r, s + i);
+			r->x += s[i];
+			r->y += s[i + 1];
+			cff_line(r);
+			r->sp = 0;
+			break;
+		}
+		case 25: { /* rlinecurve */
+			if (!r->moved || n < 8 || ((n - 6) & 1))
+				return 0;
+			int i = 0;
+			for (; i + 2 <= n - 6; i += 2) {
+				r->x += s[i];
+				r->y += s[i + 1];
+				cff_line(r);
+			}
+			cff_rcurve(r, s + i);
+			r->sp = 0;
+			break;
+		}
+		case 26: case 27: { /* vvcurveto, hhcurveto */
+			if (!r->moved)
+				return 0;
+			int i = 0, vertical = op == 26;
+			if (n & 1) {
+				if (vertical)
+					r->x += s[0];
+				else
+					r->y += s[0];
+				i = 1;
+			}
+			if ((n - i) % 4)
+				return 0;
+			for (; i < n; i += 4) {
+				float x1, y1, x2, y2;
+				if (vertical) {
+					x1 = r->x, y1 = r->y + s[i];
+					x2 = x1 + s[i + 1], y2 = y1 + s[i + 2];
+					r->x = x2;
+					r->y = y2 + s[i + 3];
+				} else {
+					x1 = r->x + s[i], y1 = r->y;
+					x2 = x1 + s[i + 1], y2 = y1 + s[i + 2];
+					r->x = x2 + s[i + 3];
+					r->y = y2;
+				}
+				cff_curve(r, x1, y1, x2, y2);
+			}
+			r->sp = 0;
+			break;
+		}
+		case 30: case 31: { /* vhcurveto, hvcurveto */
+			if (!r->moved || n < 4)
+				return 0;
+			int i = 0, horizontal = op == 31;
+			while (i < n) {
+				int left = n - i;
+				if (left < 4)
+					return 0;
+				float extra = left == 5 ? s[i + 4] : 0.0f, x1, y1, x2, y2;
+				if (horizontal) {
+					x1 = r->x + s[i], y1 = r->y;
+					x2 = x1 + s[i + 1], y2 = y1 + s[i + 2];
+					r->y = y2 + s[i + 3];
+					r->x = x2 + extra;
+				} else {
+					x1 = r->x, y1 = r->y + s[i];
+					x2 = x1 + s[i + 1], y2 = y1 + s[i + 2];
+					r->x = x2 + s[i + 3];
+					r->y = y2 + extra;
+				}
+				cff_curve(r, x1, y1, x2, y2);
+				i += left == 5 ? 5 : 4;
+				horizontal = !horizontal;
+			}
+			r->sp = 0;
+			break;
+		}
+		case 10: case 29: { /* callsubr, callgsubr */
+			if (n == 0 || depth == 10)
+				return 0;
+			const cff_index *ix = op == 29 ? &r->font->gsubrs : (r->have_lsubrs ? &r->lsubrs : NULL);
+			if (!ix)
+				return 0;
+			float fi = s[--r->sp];
+			long bias = ix->count < 1240 ? 107 : (ix->count < 33900 ? 1131 : 32768);
+			long idx = (long)fi + bias;
+			span sub;
+			if ((float)(long)fi != fi || idx < 0 || !cff_get(ix, (uint32_t)idx, &sub) || !cff_exec(r, sub, depth + 1))
+				return 0;
+			if (r->ended)
+				return p == cs.len;
+			break;
+		}
+		case 11: /* return */
+			return 1;
+		case 14: /* endchar */
+			if (n == 4 || (!r->width_seen && n == 5)) { /* seac: base glyph, then the accent at (adx, ady) */
+				const float *a = s + (n - 4);
+				r->width_seen = 1;
+				r->sp = 0;
+				if (depth == 10 || !(a[2] >= 0 && a[2] <= 255 && a[3] >= 0 && a[3] <= 255))
+					return 0;
+				if (r->path_open) {
+					r->path_open = 0;
+					cff_emit(r, VGO_CLOSE, 0, 0, 0, 0, 0, 0);
+				}
+				if (!cff_component(r, cff_std_glyph(r->font, (int)a[2]), 0.0f, 0.0f, depth) ||
+				    !cff_component(r, cff_std_glyph(r->font, (int)a[3]), a[0], a[1], depth))
+					return 0;
+				r->ended = 1;
+				return p == cs.len;
+			}
+			if (n == 1 && !r->width_seen)
+				r->width_seen = 1;
+			r->sp = 0;
+			if (r->path_open) {
+				r->path_open = 0;
+				cff_emit(r, VGO_CLOSE, 0, 0, 0, 0, 0, 0);
+			}
+			r->ended = 1;
+			return p == cs.len;
+		case 12: {
+			if (p >= cs.len || !r->moved)
+				return 0;
+			uint8_t op2 = cs.p[p++];
+			float x0 = r->x, y0 = r->y;
+			if (op2 == 35 && n == 13) { /* flex */
+				cff_rcurve(r, s);
+				cff_rcurve(r, s + 6);
+			} else if (op2 == 34 && n == 7) { /* hflex */
+				float a1[6] = {s[0], 0, s[1], s[2], s[3], 0};
+				cff_rcurve(r, a1);
+				float x1 = r->x + s[4], x2 = x1 + s[5];
+				r->x = x2 + s[6];
+				float yy = r->y;
+				r->y = y0;
+				cff_curve(r, x1, yy, x2, y0);
+			} else if (op2 == 36 && n == 9) { /* hflex1 */
+				float a1[6] = {s[0], s[1], s[2], s[3], s[4], 0};
+				cff_rcurve(r, a1);
+				float x1 = r->x + s[5], y1 = r->y, x2 = x1 + s[6], y2 = y1 + s[7];
+				r->x = x2 + s[8];
+				r->y = y0;
+				cff_curve(r, x1, y1, x2, y2);
+			} else if (op2 == 37 && n == 11) { /* flex1 */
+				cff_rcurve(r, s);
+				float x1 = r->x + s[6], y1 = r->y + s[7], x2 = x1 + s[8], y2 = y1 + s[9];
+				if (fabsf(x2 - x0) > fabsf(y2 - y0)) {
+					r->x = x2 + s[10];
+					r->y = y0;
+				} else {
+					r->x = x0;
+					r->y = y2 + s[10];
+				}
+				cff_curve(r, x1, y1, x2, y2);
+			} else {
+				return 0;
+			}
+			r->sp = 0;
+			break;
+		}
+		default:
+			return 0;
+		}
+	}
+	return 1;
+}
+
+/* number of commands written to the sink (whatever ttf-parser's Option says: the reference ignores it) */
+static void cff_outline(const vgo_font *f, int gid, cmd_sink *sink)
+{
+	cff_font c;
+	span cs;
+	if (!cff_open(f->cff, &c) || gid < 0 || !cff_get(&c.chars, (uint32_t)gid, &cs))
+		return;
+	cff_run r;
+	memset(&r, 0, sizeof r);
+	r.font = &c;
+	r.sink = sink;
+	r.have_lsubrs = cff_glyph_lsubrs(&c, gid, &r.lsubrs);
+	(void)cff_exec(&r, cs, 0);
+}
+
 int vgo_font_outline(const vgo_font *f, int gid, vgo_cmd *out, int cap)
 {
 	cmd_sink sink = {out, cap, 0};
 	span g;
+	if (!(f->glyf.p && f->loca.p) && f->cff.p) { /* ttf-parser: glyf first, then cff */
+		cff_outline(f, gid, &sink);
+		return sink.n;
+	}
 	if (!glyph_data(f, gid, &g))
 		return 0;
 	outline_impl(f, g, 0, &sink, XF_ID);

@@ -150,7 +150,7 @@ def test_every_operator_hints_widths_and_subroutines(vg, ops_cff):
     assert got[0x46] == []                               # "empty": no callbacks -> PbfGlyph::empty (renderer.rs:118-120)
 
 
-def test_seac_accented_glyphs(vg):
+def test_seac_accented_glyphs(oracle, vg):
     """`adx ady bchar achar endchar`: the base glyph and the accent (codes of the StandardEncoding, looked up through the
     charset) drawn one after the other, the accent moved by (adx, ady) — against fontTools' decomposition"""
     from fontTools.pens.recordingPen import DecomposingRecordingPen
@@ -186,9 +186,46 @@ def test_seac_accented_glyphs(vg):
                 want.append((Z, 0, 0, 0, 0, 0, 0))
         assert got[cp] == want, name
     assert sum(1 for t in got[0xC1] if t[0] == M) == 2 and sum(1 for t in got[0xC4] if t[0] == M) == 3
+    assert _oracle_callbacks(oracle, font) == got
 
 
-def test_cid_keyed_font(vg, ops_cff):
+def _oracle_callbacks(oracle, font_bytes):
+    f = oracle.Font(font_bytes)
+    out = {}
+    for cp in f.codepoints():
+        seq = f.outline(f.glyph_index(int(cp)))
+        out[int(cp)] = [(k,) + ((0.0,) * 6 if k == Z else (x1, y1, x2, y2, x, y)) for k, x1, y1, x2, y2, x, y in seq]
+    return out
+
+
+def test_three_readers_agree(oracle, vg, fira_cff, ops_cff):
+    """the oracle's C reader (written on its own from the same technical notes), the product's C++ reader and fontTools
+    emit the same callbacks for every mapped glyph of the synthesised fonts"""
+    for font in (fira_cff, ops_cff):
+        want = _fonttools_callbacks(font)
+        got, _ = _product_callbacks(vg, font)
+        orc = _oracle_callbacks(oracle, font)
+        assert set(orc) == set(want) == set(got)
+        for cp in want:
+            assert orc[cp] == want[cp] == got[cp], hex(cp)
+
+
+def test_cff_font_to_pbf_product_equals_oracle(oracle, vg, fira_cff):
+    """whole path on a CFF font with the dummy raster (CPU): every PBF file of the product equals the oracle's"""
+    mgr = vg.FontManager(True)
+    fid = mgr.add_font_data("Fira CFF", fira_cff)
+    w = vg.DummyWriter()
+    mgr.render_glyphs(w, vg.Renderer.new_dummy())
+    font = oracle.Font(fira_cff)
+    n_glyphs = 0
+    for blk in range(256):
+        want, n, _ = oracle.render_block([font], fid, blk * 256, oracle.DUMMY)
+        assert w.files[f"{fid}/{blk * 256}-{blk * 256 + 255}.pbf"] == want, blk
+        n_glyphs += n
+    assert n_glyphs > 250
+
+
+def test_cid_keyed_font(oracle, vg, ops_cff):
     """the same charstrings behind ROS / FDArray / FDSelect (local subroutines come from the glyph's font dict)"""
     from fontTools.cffLib import FDArrayIndex, FDSelect, FontDict
     f = TTFont(io.BytesIO(ops_cff))
@@ -220,8 +257,9 @@ def test_cid_keyed_font(vg, ops_cff):
     assert hasattr(check["CFF "].cff.topDictIndex[0], "ROS")
     want = _fonttools_callbacks(ops_cff)
     got, _ = _product_callbacks(vg, cid)
+    orc = _oracle_callbacks(oracle, cid)
     for cp in range(0x41, 0x46):
-        assert got[cp] == want[cp], hex(cp)
+        assert got[cp] == want[cp] == orc[cp], hex(cp)
 
 
 def test_unreadable_outline_tables_are_refused(vg, fira_cff):
@@ -239,6 +277,7 @@ import numpy as np
 ROOT = Path(sys.argv[1]); font = Path(sys.argv[2]).read_bytes(); seed = int(sys.argv[3])
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from conftest import load_product
+from oracle import oracle as O
 vg = load_product()
 rng = np.random.default_rng(seed)
 at = font.index(b"CFF ")
@@ -264,6 +303,12 @@ for i in range(150):
     except RuntimeError:
         pass
     ok += 1
+    try:  # the oracle's own reader on the same bytes
+        f = O.Font(bytes(b))
+    except Exception:
+        continue
+    for cp in f.codepoints()[:300]:
+        f.prepare_glyph(int(cp))
 assert ok >= 1
 print(f"{ok} loaded, {bad} rejected")
 """
@@ -281,6 +326,19 @@ def test_damaged_cff_tables_never_crash(tmp_path, fira_cff, seed):
     p = subprocess.run([sys.executable, "-c", _CHILD, str(ROOT), str(path), str(seed)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, f"child died with {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
     assert "loaded" in p.stdout
+
+
+@pytest.mark.gpu
+def test_cff_font_to_pbf_on_the_gpu_equals_oracle(oracle, vg, fira_cff):
+    """fonts -> PBF bytes through the HIP renderer (device front-end, cubics flattened on the GPU) = the oracle's files"""
+    mgr = vg.FontManager(True)
+    fid = mgr.add_font_data("Fira CFF", fira_cff)
+    w = vg.DummyWriter()
+    mgr.render_glyphs(w, vg.Renderer.new_precise(0))
+    font = oracle.Font(fira_cff)
+    for blk in range(256):
+        want, _, _ = oracle.render_block([font], fid, blk * 256, oracle.PRECISE)
+        assert w.files[f"{fid}/{blk * 256}-{blk * 256 + 255}.pbf"] == want, blk
 
 
 @pytest.mark.gpu
