@@ -3,7 +3,9 @@
  *
  * Scalar f64 restatement of the reference's per-glyph SDF path.  Every function cites
  * the reference file:line it follows (paths relative to /root/reference/).  Compile
- * with -ffp-contract=off (Rust never fuses a*b+c).
+ * with -ffp-contract=off (Rust never fuses a*b+c).  The `CFF ` reader further down restates a
+ * third-party crate's behaviour from Adobe's technical notes; no reference fixture pins it
+ * (parity unpinned, see its header comment).
  */
 #define _POSIX_C_SOURCE 200809L
 #include "vg_oracle.h"
