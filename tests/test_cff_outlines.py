@@ -225,6 +225,21 @@ def test_cff_font_to_pbf_product_equals_oracle(oracle, vg, fira_cff):
     assert n_glyphs > 250
 
 
+def test_scan_picks_up_otf_files(vg, tmp_path, fira_cff):
+    """recurse.rs:104-133 takes `.ttf` and `.otf`: an OpenType/CFF file in a scanned directory becomes a font named by its
+    own name table and renders (index.json lists it)"""
+    import json
+    (tmp_path / "fonts").mkdir()
+    (tmp_path / "fonts" / "Synth CFF - Regular.otf").write_bytes(fira_cff)
+    mgr = vg.FontManager(True)
+    mgr.scan(tmp_path / "fonts")
+    assert mgr.font_ids() == ["synth_cff_regular"]
+    w = vg.DummyWriter()
+    mgr.render_glyphs(w, vg.Renderer.new_dummy())
+    assert len(w.files) == 256
+    assert json.loads(mgr.index_json()) == ["synth_cff_regular"]
+
+
 def test_cid_keyed_font(oracle, vg, ops_cff):
     """the same charstrings behind ROS / FDArray / FDSelect (local subroutines come from the glyph's font dict)"""
     from fontTools.cffLib import FDArrayIndex, FDSelect, FontDict
