@@ -26,6 +26,47 @@ def test_parse_font_name_reference_expectations(vg):
         assert got == (want_family, want_style, int(want_weight), want_width), ln
 
 
+def test_stripped_words_are_exactly_the_reference_set(vg):
+    """parse_font_name.rs:21-186, :266-271: the words stripped from a family decide the font id (output directory,
+    font_families.json).  Every one of the reference's 159 tokens is stripped, and words that LOOK like script names
+    but are not in its table stay (rounds 1-2 stripped a superset derived from UAX #24)."""
+    toks = [ln for ln in (GOLDEN / "script_tokens.txt").read_text().splitlines() if ln and not ln.startswith("#")]
+    assert len(toks) == 159 and toks == sorted(toks)
+    for t in toks:
+        assert vg.parse_font_name(f"Xy {t.capitalize()} Zq", "XyZq-Regular") == ("Xy Zq", "normal", 400, "normal"), t
+    kept = ("han hangul hiragana katakana braille bopomofo hk toto viet kawi numerals arabian nagri citi akuru dives dogra "
+            "chorasmian minoan cypro nandinagari nag mundari nyiakeng puachue tangsa uyghur vithkuqi yezidi signwriting "
+            "makasar khitan small script cursive siyaq latin greek cyrillic symbols2 display mono serif").split()
+    assert not set(kept) & set(toks)
+    for t in kept:
+        assert vg.parse_font_name(f"Xy {t.capitalize()}", "Xy-Regular")[0] == f"Xy {t.capitalize()}", t
+    # to_lowercase is Unicode: KELVIN SIGN lower-cases to 'k'
+    assert vg.parse_font_name("Noto Sans \u212aR", "x-Regular")[0] == "Noto Sans"
+
+
+def test_family_names_outside_the_reference_tests(vg):
+    """Rows derived by applying the reference's algorithm (parse_font_name.rs:214-291) and its token table by hand;
+    not rows of the reference's own test.  ADVICE r2: 'Source Han Sans' must not collapse into 'Source Sans'."""
+    for family, ps, want in (
+        ("Source Han Sans", "SourceHanSans-Regular", ("Source Han Sans", "normal", 400, "normal")),
+        ("Source Han Sans HK", "SourceHanSansHK-Bold", ("Source Han Sans HK", "normal", 700, "normal")),
+        ("Noto Sans Hangul", "NotoSansHangul-Regular", ("Noto Sans Hangul", "normal", 400, "normal")),
+        ("Braille Institute", "BrailleInstitute-Regular", ("Braille Institute", "normal", 400, "normal")),
+        ("Noto Sans Toto", "NotoSansToto-Regular", ("Noto Sans Toto", "normal", 400, "normal")),
+        ("Toto Display", "TotoDisplay-Italic", ("Toto Display", "italic", 400, "normal")),
+        ("Old Arabian Nights", "OldArabianNights", ("Arabian Nights", "normal", 400, "normal")),
+        ("Noto Sans Tai Viet", "NotoSansTaiViet-Regular", ("Noto Sans Viet", "normal", 400, "normal")),
+        ("Noto Sans Syloti Nagri", "NotoSansSylotiNagri-Regular", ("Noto Sans Nagri", "normal", 400, "normal")),
+        ("Noto Sans Warang Citi", "NotoSansWarangCiti-Regular", ("Noto Sans Citi", "normal", 400, "normal")),
+        ("Noto Sans Mayan Numerals", "NotoSansMayanNumerals-Regular", ("Noto Sans Numerals", "normal", 400, "normal")),
+        ("Noto Sans Old South Arabian", "NotoSansOldSouthArabian-Regular", ("Noto Sans Arabian", "normal", 400, "normal")),
+        ("Noto Sans Symbols2", "NotoSansSymbols2-Regular", ("Noto Sans Symbols2", "normal", 400, "normal")),
+        ("Noto Serif Khitan Small Script", "NotoSerifKhitanSmallScript-Regular", ("Noto Serif Khitan Small Script", "normal", 400, "normal")),
+    ):
+        assert vg.parse_font_name(family, ps) == want, family
+    assert vg.name_to_id("Source Han Sans Regular") == "source_han_sans_regular"
+
+
 def test_parse_font_name_rules(vg):
     # doc example, parse_font_name.rs:203-213
     assert vg.parse_font_name("Open Sans SemiCondensed Light", "OpenSansSemiCondensed-LightItalic") == \

@@ -9,51 +9,43 @@ namespace vg {
 namespace {
 
 // ---------------------------------------------------------------------------------------
-// Script names.  Font projects that ship one file per script (Noto: "Noto Sans Tamil", "Noto Sans
-// Old Italic", "Noto Sans JP", ...) put the script's name behind the family; the reference strips
-// those words so that all subsets share one family (parse_font_name.rs:266-271, word by word).
-// This table is written from the Unicode Standard's script names (UAX #24, Scripts.txt long
-// names, underscores as spaces), not from the reference's word list; it is split into
-// lower-case words at first use.  Left out on purpose: Latin, Greek, Cyrillic (the base
-// file's own scripts, never a suffix), Common / Inherited / Unknown, and words of one letter
-// ("Linear A").  The second list holds suffixes that are not script names but occur in the
-// reference's own test expectations (tests/golden/font_names.csv) or in Noto's file naming.
+// Words stripped from a family name.  Font projects that ship one file per script (Noto: "Noto Sans
+// Tamil", "Noto Sans Old Italic", "Noto Sans JP", ...) put the script's name behind the family; the
+// reference strips those words so that all subsets share one family (parse_font_name.rs:266-271, word
+// by word against SCRIPT_TOKENS, :21-186).  Which words go decides the font id, hence the output
+// directory and font_families.json, so the SET is part of the output contract: it is exactly the
+// reference's 159 words (tests/golden/script_tokens.txt pins it; rounds 1-2 derived a superset from
+// UAX #24 and turned "Source Han Sans" into "Source Sans").  One string, split at first use.
 // ---------------------------------------------------------------------------------------
-const char *const kUnicodeScripts[] = {
-	"Adlam", "Ahom", "Anatolian Hieroglyphs", "Arabic", "Armenian", "Avestan", "Balinese", "Bamum", "Bassa Vah",
-	"Batak", "Bengali", "Bhaiksuki", "Bopomofo", "Brahmi", "Braille", "Buginese", "Buhid", "Canadian Aboriginal",
-	"Carian", "Caucasian Albanian", "Chakma", "Cham", "Cherokee", "Chorasmian", "Coptic", "Cuneiform", "Cypriot",
-	"Cypro Minoan", "Deseret", "Devanagari", "Dives Akuru", "Dogra", "Duployan", "Egyptian Hieroglyphs", "Elbasan",
-	"Elymaic", "Ethiopic", "Georgian", "Glagolitic", "Gothic", "Grantha", "Gujarati", "Gunjala Gondi", "Gurmukhi",
-	"Han", "Hangul", "Hanifi Rohingya", "Hanunoo", "Hatran", "Hebrew", "Hiragana", "Imperial Aramaic",
-	"Inscriptional Pahlavi", "Inscriptional Parthian", "Javanese", "Kaithi", "Kannada", "Katakana", "Kawi", "Kayah Li",
-	"Kharoshthi", "Khitan Small Script", "Khmer", "Khojki", "Khudawadi", "Lao", "Lepcha", "Limbu", "Linear A",
-	"Linear B", "Lisu", "Lycian", "Lydian", "Mahajani", "Makasar", "Malayalam", "Mandaic", "Manichaean", "Marchen",
-	"Masaram Gondi", "Medefaidrin", "Meetei Mayek", "Mende Kikakui", "Meroitic Cursive", "Meroitic Hieroglyphs",
-	"Miao", "Modi", "Mongolian", "Mro", "Multani", "Myanmar", "Nabataean", "Nag Mundari", "Nandinagari", "New Tai Lue",
-	"Newa", "Nko", "Nushu", "Nyiakeng Puachue Hmong", "Ogham", "Ol Chiki", "Old Hungarian", "Old Italic",
-	"Old North Arabian", "Old Permic", "Old Persian", "Old Sogdian", "Old South Arabian", "Old Turkic", "Old Uyghur",
-	"Oriya", "Osage", "Osmanya", "Pahawh Hmong", "Palmyrene", "Pau Cin Hau", "Phags Pa", "Phoenician",
-	"Psalter Pahlavi", "Rejang", "Runic", "Samaritan", "Saurashtra", "Sharada", "Shavian", "Siddham", "SignWriting",
-	"Sinhala", "Sogdian", "Sora Sompeng", "Soyombo", "Sundanese", "Syloti Nagri", "Syriac", "Tagalog", "Tagbanwa",
-	"Tai Le", "Tai Tham", "Tai Viet", "Takri", "Tamil", "Tangsa", "Tangut", "Telugu", "Thaana", "Thai", "Tibetan",
-	"Tifinagh", "Tirhuta", "Toto", "Ugaritic", "Vai", "Vithkuqi", "Wancho", "Warang Citi", "Yezidi", "Yi",
-	"Zanabazar Square",
-};
-const char *const kOtherSuffixes[] = {
-	"JP", "KR", "SC", "TC", "HK",    // CJK region editions
-	"Italic",                        // a style word, never part of a family ("Old Italic" once "Old" is gone)
-	"Symbols", "Mayan Numerals", "Indic Siyaq Numbers", // non-script Noto subsets
-};
-// words of script names that are too generic to strip from a family name
-const char *const kKeepWords[] = {"small", "script", "cursive"};
+const char kStrippedWords[] =
+	"aboriginal adlam albanian anatolian arabic aramaic armenian avestan balinese bamum bassa batak bengali "
+	"bhaiksuki brahmi buginese buhid canadian carian caucasian chakma cham cherokee chiki cin coptic cuneiform "
+	"cypriot deseret devanagari duployan egyptian elbasan elymaic ethiopic georgian glagolitic gondi gothic "
+	"grantha gujarati gunjala gurmukhi hanifi hanunoo hatran hau hebrew hieroglyphs hmong hungarian imperial "
+	"indic inscriptional italic javanese jp kaithi kannada kayah kharoshthi khmer khojki khudawadi kikakui "
+	"kr lao le lepcha li limbu linear lisu lue lycian lydian mahajani malayalam mandaic manichaean marchen "
+	"masaram mayan mayek medefaidrin meetei mende meroitic miao modi mongolian mro multani myanmar nabataean "
+	"new newa nko north numbers nushu ogham ol old oriya osage osmanya pa pahawh pahlavi palmyrene parthian "
+	"pau permic persian phags phoenician psalter rejang rohingya runic samaritan saurashtra sc sharada shavian "
+	"siddham sinhala sogdian sompeng sora south soyombo square sundanese syloti symbols syriac tagalog tagbanwa "
+	"tai takri tamil tangut tc telugu thaana thai tibetan tifinagh tirhuta turkic ugaritic vah vai wancho warang "
+	"yi zanabazar";
 
+// Rust's str::to_lowercase on the characters that can matter here: every comparison below is against ASCII
+// words, and the only non-ASCII character whose lower case is an ASCII letter is U+212A KELVIN SIGN -> 'k'.
 std::string ascii_lower(const std::string &s)
 {
-	std::string o = s;
-	for (char &c : o)
-		if (c >= 'A' && c <= 'Z')
-			c = (char)(c - 'A' + 'a');
+	std::string o;
+	o.reserve(s.size());
+	for (size_t i = 0; i < s.size(); i++) {
+		const unsigned char c = (unsigned char)s[i];
+		if (c == 0xE2 && i + 2 < s.size() && (unsigned char)s[i + 1] == 0x84 && (unsigned char)s[i + 2] == 0xAA) {
+			o.push_back('k');
+			i += 2;
+		} else {
+			o.push_back((c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a') : (char)c);
+		}
+	}
 	return o;
 }
 
@@ -61,28 +53,19 @@ const std::vector<std::string> &script_words()
 {
 	static const std::vector<std::string> words = [] {
 		std::vector<std::string> w;
-		auto add_name = [&](const char *name) {
-			std::string cur;
-			for (const char *p = name;; p++) {
-				if (*p == ' ' || *p == 0) {
-					if (cur.size() >= 2 && std::find_if(std::begin(kKeepWords), std::end(kKeepWords), [&](const char *k) {
-						                       return cur == k;
-					                       }) == std::end(kKeepWords))
-						w.push_back(cur);
-					cur.clear();
-					if (*p == 0)
-						break;
-				} else {
-					cur.push_back((*p >= 'A' && *p <= 'Z') ? (char)(*p - 'A' + 'a') : *p);
-				}
+		std::string cur;
+		for (const char *p = kStrippedWords;; p++) {
+			if (*p == ' ' || *p == 0) {
+				if (!cur.empty())
+					w.push_back(cur);
+				cur.clear();
+				if (*p == 0)
+					break;
+			} else {
+				cur.push_back(*p);
 			}
-		};
-		for (const char *n : kUnicodeScripts)
-			add_name(n);
-		for (const char *n : kOtherSuffixes)
-			add_name(n);
+		}
 		std::sort(w.begin(), w.end());
-		w.erase(std::unique(w.begin(), w.end()), w.end());
 		return w;
 	}();
 	return words;

@@ -5,9 +5,8 @@
 //   FontMetadata              src/font/metadata.rs:16-36, 89-128 (name table -> metadata)
 //   FontMetadata::generate_name   metadata.rs:43-68
 // The behaviour is pinned by the reference's own test expectations, transcribed as a fixture in
-// tests/golden/font_names.csv.  The list of script names that are stripped from a family is NOT the
-// reference's token table: it is built here from the Unicode Standard's script names (see
-// font_name.cpp), so names outside that fixture may differ — "parity unpinned" there.
+// tests/golden/font_names.csv; the set of words stripped from a family is the reference's (SCRIPT_TOKENS,
+// parse_font_name.rs:21-186; tests/golden/script_tokens.txt), since it decides font ids and directory names.
 #pragma once
 #include <cstdint>
 #include <string>
