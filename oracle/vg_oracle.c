@@ -1230,7 +1230,7 @@ static int cff_exec(cff_run *r, span cs, int depth)
 				return 0;
 			break;
 		case 21: { /* rmoveto */
-			int skip = n == 3;
+			int skip = n == 3 && !r->width_seen; /* the width operand exists once per charstring */
 			if (skip)
 				r->width_seen = 1;
 			if (!cff_moveto(r, skip, 1, 1))
@@ -1238,7 +1238,7 @@ static int cff_exec(cff_run *r, span cs, int depth)
 			break;
 		}
 		case 22: { /* hmoveto */
-			int skip = n == 2;
+			int skip = n == 2 && !r->width_seen;
 			if (skip)
 				r->width_seen = 1;
 			if (!cff_moveto(r, skip, 1, 0))
@@ -1246,7 +1246,7 @@ static int cff_exec(cff_run *r, span cs, int depth)
 			break;
 		}
 		case 4: { /* vmoveto */
-			int skip = n == 2;
+			int skip = n == 2 && !r->width_seen;
 			if (skip)
 				r->width_seen = 1;
 			if (!cff_moveto(r, skip, 0, 1))

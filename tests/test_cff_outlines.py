@@ -210,6 +210,28 @@ def test_three_readers_agree(oracle, vg, fira_cff, ops_cff):
             assert orc[cp] == want[cp] == got[cp], hex(cp)
 
 
+def test_the_width_operand_exists_once_per_charstring(oracle, vg):
+    """ttf-parser's cff1 takes a moveto's extra leading operand as the width only while no width was parsed
+    (`stack.len() == N && !width_parsed`); afterwards the stack-length check of the move fails the charstring, BEFORE its
+    close(): the callbacks emitted so far stay (renderer.rs:110 ignores outline_glyph's result).  ADVICE r2.
+    No reference fixture: parity with the crate unpinned; product and oracle are kept to the crate's published rule."""
+    names = [".notdef", "rmove", "hmove", "vmove", "hintw"]
+    progs = [[0, "hmoveto", "endchar"],
+             [500, 10, 20, "rmoveto", 30, 0, "rlineto", 0, 30, "rlineto", 7, 5, 5, "rmoveto", 10, 10, "rlineto", "endchar"],
+             [500, 10, "hmoveto", 30, 40, "rlineto", 7, 5, "hmoveto", 10, 10, "rlineto", "endchar"],
+             [500, 10, "vmoveto", 30, 40, "rlineto", 7, 5, "vmoveto", 10, 10, "rlineto", "endchar"],
+             [500, 10, 20, "hstem", 10, 20, "rmoveto", 30, 0, "rlineto", 7, 5, 5, "rmoveto", 10, 10, "rlineto", "endchar"]]
+    cs = {n: T2CharString(program=list(p)) for n, p in zip(names, progs)}
+    font = _build(names, {0x41 + i: n for i, n in enumerate(names[1:])}, cs, {n: 600 for n in names})
+    got, _ = _product_callbacks(vg, font)
+    z = (0.0,) * 4
+    assert got[0x41] == [(M,) + z + (10.0, 20.0), (L,) + z + (40.0, 20.0), (L,) + z + (40.0, 50.0)]
+    assert got[0x42] == [(M,) + z + (10.0, 0.0), (L,) + z + (40.0, 40.0)]
+    assert got[0x43] == [(M,) + z + (0.0, 10.0), (L,) + z + (30.0, 50.0)]
+    assert got[0x44] == [(M,) + z + (10.0, 20.0), (L,) + z + (40.0, 20.0)]
+    assert _oracle_callbacks(oracle, font) == got
+
+
 def test_cff_font_to_pbf_product_equals_oracle(oracle, vg, fira_cff):
     """whole path on a CFF font with the dummy raster (CPU): every PBF file of the product equals the oracle's"""
     mgr = vg.FontManager(True)

@@ -516,7 +516,7 @@ struct CharStringRun {
 			case 21: // rmoveto
 			{
 				int skip = 0;
-				if (sp == 3) {
+				if (sp == 3 && !have_width) { // (a second width operand is an error: ttf-parser checks the stack length)
 					skip = 1;
 					have_width = true;
 				}
@@ -527,7 +527,7 @@ struct CharStringRun {
 			case 22: // hmoveto
 			{
 				int skip = 0;
-				if (sp == 2) {
+				if (sp == 2 && !have_width) {
 					skip = 1;
 					have_width = true;
 				}
@@ -538,7 +538,7 @@ struct CharStringRun {
 			case 4: // vmoveto
 			{
 				int skip = 0;
-				if (sp == 2) {
+				if (sp == 2 && !have_width) {
 					skip = 1;
 					have_width = true;
 				}
