@@ -279,3 +279,51 @@ def test_whole_run_into_tar_and_directory_equals_the_dummy_writer(vg, tmp_path):
     dw.close()
     on_disk = {str(p.relative_to(out_dir)): p.read_bytes() for p in out_dir.rglob("*") if p.is_file()}
     assert on_disk == ref.files
+
+
+@pytest.mark.gpu
+def test_whole_run_with_the_hip_renderer_into_tar_and_directory(vg, tmp_path):
+    """SURVEY §8f ranks 3 + 4 through the HIP path (recurse.rs:70-101): scan(testdata) -> render_glyphs_to(native tar
+    writer, Renderer::new_precise) -> index.json -> font_families.json -> finish.  Every tar member is compared with the
+    committed golden SHA-256 of its block (tests/golden/pbf_sha256.json: `fira`, and `noto_all` = the 20 Noto files the scan
+    merges into noto_sans_regular), the JSON text with the CPU-side builders, and the same run into a directory tree with
+    the tar's contents.  Both dispatchers (device front-end and host tessellation) are driven."""
+    import hashlib
+    golden = json.loads((GOLDEN / "pbf_sha256.json").read_text())
+    want = {f"fira_sans_regular/{s}-{int(s) + 255}.pbf": h for s, h in golden["fira"].items()}
+    want.update({f"noto_sans_regular/{s}-{int(s) + 255}.pbf": h for s, h in golden["noto_all"].items()})
+    r = vg.Renderer.new_precise(0)
+    for fe in (True, False):
+        m = vg.FontManager(True)
+        m.scan(TESTDATA)
+        m.set_device_front_end(fe)
+        tar_path = tmp_path / f"glyphs{int(fe)}.tar"
+        tw = vg.NativeWriter.new_tar(tar_path, 1234567890)
+        m.render_glyphs_to(tw, r)
+        m.write_index_json(tw)
+        m.write_families_json(tw)
+        tw.finish()
+        tw.close()
+        with tarfile.open(tar_path) as tf:
+            members = tf.getmembers()
+            assert all(mm.mtime == 1234567890 for mm in members)
+            names = [mm.name + ("/" if mm.isdir() else "") for mm in members]
+            got = {mm.name: tf.extractfile(mm).read() for mm in members if mm.isfile()}
+        assert names[0] == "fira_sans_regular/" and names[257] == "noto_sans_regular/" and names[-2:] == ["index.json", "font_families.json"]
+        assert len(got) == 2 * 256 + 2
+        bad = [n for n, h in want.items() if hashlib.sha256(got[n]).hexdigest() != h]
+        assert not bad, f"front-end {fe}: {len(bad)} files differ from the golden SHA-256: {bad[:5]}"
+        assert got["index.json"] == m.index_json() and got["font_families.json"] == m.families_json()
+        assert json.loads(got["index.json"]) == ["fira_sans_regular", "noto_sans_regular"]
+        assert os.path.getsize(tar_path) % 512 == 0
+
+        out_dir = tmp_path / f"tree{int(fe)}"
+        out_dir.mkdir()
+        dw = vg.NativeWriter.new_file(out_dir)
+        m.render_glyphs_to(dw, r)
+        m.write_index_json(dw)
+        m.write_families_json(dw)
+        dw.finish()
+        dw.close()
+        on_disk = {str(p.relative_to(out_dir)): p.read_bytes() for p in out_dir.rglob("*") if p.is_file()}
+        assert on_disk == got
