@@ -309,7 +309,7 @@ def test_whole_run_with_the_hip_renderer_into_tar_and_directory(vg, tmp_path):
             assert all(mm.mtime == 1234567890 for mm in members)
             names = [mm.name + ("/" if mm.isdir() else "") for mm in members]
             got = {mm.name: tf.extractfile(mm).read() for mm in members if mm.isfile()}
-        assert names[0] == "fira_sans_regular/" and names[257] == "noto_sans_regular/" and names[-2:] == ["index.json", "font_families.json"]
+        assert names[:2] == ["fira_sans_regular/", "noto_sans_regular/"] and names[-2:] == ["index.json", "font_families.json"]
         assert len(got) == 2 * 256 + 2
         bad = [n for n, h in want.items() if hashlib.sha256(got[n]).hexdigest() != h]
         assert not bad, f"front-end {fe}: {len(bad)} files differ from the golden SHA-256: {bad[:5]}"

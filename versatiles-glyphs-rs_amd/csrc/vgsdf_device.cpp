@@ -40,6 +40,21 @@ inline bool is_pinned(const void *p, size_t bytes)
 	return true;
 }
 
+// The address a KERNEL may use for page-locked host memory: the mapping the runtime reports for it (equal to the host
+// address for hipHostMalloc memory on this platform, but not guaranteed for memory the caller registered itself with
+// hipHostRegister).  NULL when p is not page-locked host memory known to HIP, or has no device mapping.
+inline void *pinned_device_ptr(void *p, size_t bytes)
+{
+	if (!is_pinned(p, bytes))
+		return nullptr;
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return a.devicePointer;
+}
+
 } // namespace
 
 struct vgsdf_ctx {
@@ -108,6 +123,7 @@ struct FePending {
 	uint32_t n = 0, n_cmds = 0;
 	size_t hdr_off = 0, rh_bytes = 0;
 	bool span = false, spec = false;
+	bool spec_direct = false; // the raster stores through the device mapping of the caller's page-locked buffer
 	uint8_t *spec_out = nullptr, *d_spec = nullptr; // destination of the raster enqueued behind the front-end
 	size_t spec_cap = 0;
 	uint32_t launch_spans = 0, span_max = 4, span_budget = 16;
@@ -983,8 +999,9 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	// buffer itself or, for pageable memory, the context's device buffer
 	p.spec = spec_out != nullptr && spec_cap != 0 && ctx->variant == 0;
 	if (p.spec) {
-		if (is_pinned(spec_out, spec_cap)) {
-			p.d_spec = spec_out;
+		if (void *mapped = pinned_device_ptr(spec_out, spec_cap)) {
+			p.d_spec = (uint8_t *)mapped;
+			p.spec_direct = true;
 		} else {
 			FE_TRY(fe.out.ensure(spec_cap + 16));
 			p.d_spec = (uint8_t *)fe.out.p;
@@ -1106,7 +1123,7 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	b.tile_order = 1; // the device-built list is dispatched in list order
 	fe.last_spans = hdr.n_spans;
 	const bool done = p.spec && hdr.ok != 0; // the raster behind the plan ran over the whole list
-	if (!(done && p.d_spec == p.spec_out))
+	if (!(done && p.spec_direct))
 		FE_TRY(fe.out.ensure(std::max((size_t)fe.out_bytes, done ? p.spec_cap : (size_t)0) + 16));
 	b.d_glyphs = d.descs;
 	b.d_tiles = (uint2 *)fe.tiles.p;
@@ -1125,7 +1142,7 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	if (p.spec_out && fe.out_bytes <= p.spec_cap) {
 		int rc = VGSDF_OK;
 		if (done) {
-			if (p.d_spec != p.spec_out && fe.out_bytes) { // pageable destination: the raster wrote the device buffer
+			if (!p.spec_direct && fe.out_bytes) { // pageable destination: the raster wrote the device buffer
 				FE_TRY(hipMemcpyAsync(p.spec_out, p.d_spec, (size_t)fe.out_bytes, hipMemcpyDeviceToHost, st));
 				FE_TRY(hipStreamSynchronize(st));
 			}
@@ -1141,7 +1158,7 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	}
 	if (trace && p.spec_out)
 		std::fprintf(stderr, "[vgsdf] one submission%s, %s destination\n", done ? "" : " (guess too small: second launches)",
-		             p.d_spec == p.spec_out ? "page-locked" : "pageable");
+		             p.spec_direct ? "page-locked" : "pageable");
 	if (trace)
 		std::fprintf(stderr, "[vgsdf] prepare: validate %.3f ms, submit ... read-back %.3f ms, second launches%s%s %.3f ms, host %.3f ms\n",
 		             (p.t1 - p.t0) * 1e3, (tr2 - p.t1) * 1e3, replan ? " (plan)" : "", reemit ? " (emit)" : "", (tr3 - tr2) * 1e3,
