@@ -16,8 +16,11 @@ Regular, full codepoint set, 1xMI355X").  value = glyphs/s over all ranks.
                     FontManager.shard_glyphs; BASELINE.json configs[3]:
                     `--workload noto_all --sharded`): strong scaling, total work fixed.
 
-The timed region is at least --min-ms long (default 50 ms): if K steps are shorter, more steps are
-timed and `steps` says how many (`steps_requested` = K).  Rank 0 prints ONE JSON line.  The CPU
+Exactly K steps are timed (W untimed warm-up launches first); `steady` repeats the measurement over a region of at
+least --min-ms (default 50 ms) and is reported beside the headline, never as `value`.  With --gpus N > 1 the same
+line also carries config 4 (`sharded_noto_all`: ONE font's glyphs split over the ranks, strong scaling), config 5
+(`synthetic_ranges`: rank r renders outlines [8192 r, 8192 (r + 1)) of the 65 536) and `in_library` (rank 0 alone
+drives all N devices through the C ABI's one-process form, vg_renderer_new_multi).  Rank 0 prints ONE JSON line.  The CPU
 baseline leg (rank 0, N=1 only) times the oracle — the C restatement of the reference algorithm,
 oracle/ — on the same tessellated batch on the host cores; the oracle is never on the measured path.
 """
@@ -72,7 +75,7 @@ def kernel_source_sha256():
     """Identity of the raster kernel's code: the PMC-derived numbers in profiles/traffic.json are only
     reported when they were collected on exactly these sources."""
     h = hashlib.sha256()
-    for f in ("sdf_kernels.hip", "sdf_kernels.h"):
+    for f in ("sdf_kernels.hip", "sdf_span_kernel.inc", "sdf_kernels.h"):
         h.update((ROOT / "versatiles-glyphs-rs_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()
 
@@ -98,16 +101,14 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def time_resident(ctx, db, steps, warmup, min_ms):
-    """W warm-up launches, then K' >= K launches with K' chosen so that the region lasts >= min_ms.
-    -> (steps timed, HIP-event ms of those launches)"""
+def steps_for(ctx, db, warmup, min_ms):
+    """W warm-up launches, then the number of launches a region of >= min_ms needs (side measurements only: the headline
+    times exactly --steps)"""
     for _ in range(max(warmup, 0)):
         db.launch()
     ctx.sync()
-    probe = max(1, min(steps, 50))
-    est = db.time(probe) / probe  # ms per launch (untimed probe; the first launches of a run are slower than the rest)
-    k = max(steps, int(1.15 * min_ms / max(est, 1e-6)) + 1)
-    return k, est
+    est = db.time(10) / 10  # ms per launch (untimed probe)
+    return int(1.15 * min_ms / max(est, 1e-6)) + 1
 
 
 def main():
@@ -207,29 +208,130 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    steps, _ = time_resident(ctx, db, args.steps, args.warmup, args.min_ms)
-    if dist is not None:  # every rank times the same number of steps
-        k = torch.tensor([steps], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        steps = int(k.item())
+    def timed(dbatch, k, w):
+        """W untimed launches, then EXACTLY k launches between barrier + synchronize on both sides.
+        -> (wall seconds, max over ranks; HIP-event ms of this rank's k launches)"""
+        for _ in range(max(w, 0)):
+            dbatch.launch()
+        ctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        ms = dbatch.time(k)            # HIP events on the launch stream around the k launches; waits for the last
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, ms
 
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms_total = db.time(steps)   # HIP events on the launch stream, K' launches, waits for the last
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def all_sum(vals):
+        if dist is None:
+            return [int(v) for v in vals]
+        c = torch.tensor(vals, dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        return [int(v) for v in c.tolist()]
 
-    counters = [256, st["n_glyphs"], st["n_pixels"]]   # blocks, glyphs, pixels rendered per step by this rank
+    # The long side measurement runs FIRST: a region of >= --min-ms (every rank times the same number of steps).  It also
+    # brings the GPU to its sustained clocks — the first launches after an idle period run ~8 % slower (measured: 85.9 us
+    # per launch in a cold 20-step region against 79.0 us sustained) — so the headline's W + K launches below measure
+    # the kernel the way a renderer that is busy rendering meets it.
+    k_long = steps_for(ctx, db, args.warmup, args.min_ms)
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        c = torch.tensor(counters, dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)        # the only RCCL payload: 24 bytes
-        counters = [int(v) for v in c.tolist()]
-        if args.sharded:
-            counters[0] = 256                           # one font's blocks, whoever assembles them
+        kk = torch.tensor([k_long], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+        k_long = int(kk.item())
+    steady_elapsed, steady_ms = timed(db, k_long, 0)
+    # headline: W untimed warm-up steps, then EXACTLY --steps steps
+    steps = args.steps
+    elapsed, kernel_ms_total = timed(db, steps, args.warmup)
+    counters = all_sum([256, st["n_glyphs"], st["n_pixels"]])   # blocks, glyphs, pixels per step; the only RCCL payload: 24 bytes
+    if dist is not None and args.sharded:
+        counters[0] = 256                               # one font's blocks, whoever assembles them
+
+    # ---- N > 1: configs 4 and 5 of BASELINE.json, measured by every rank, reported by rank 0 in the same line ----
+    multi = {}
+    if world > 1 and not args.sharded and not synthetic and not args.no_configs:
+        # config 4: Noto Sans all languages, ONE font's glyphs sharded over the ranks (strong scaling)
+        d4, p4 = workload_files("noto_all")
+        m4 = vg.FontManager(True)
+        f4 = m4.add_font_with_name(d4, p4)
+        owner, est = m4.shard_glyphs(f4, world)
+        loads = [float(est[owner == r].sum()) for r in range(world)]
+        m4.set_glyph_shard(rank, world)
+        hb4 = m4.build_batch(f4)
+        db4 = ctx.upload(hb4.batch)
+        st4 = db4.stats()
+        k4 = max(10, steps_for(ctx, db4, 5, args.min_ms))
+        if dist is not None:
+            kk = torch.tensor([k4], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+            k4 = int(kk.item())
+        el4, ms4 = timed(db4, k4, 0)
+        c4 = all_sum([st4["n_glyphs"], st4["n_pixels"], st4["alg_bytes"]])
+        multi["sharded_noto_all"] = {
+            "config": "BASELINE.json configs[3]: Noto Sans all languages (20 files, one logical font), glyphs sharded over the ranks",
+            "scaling": "strong", "steps": k4, "ms_per_step": el4 / k4 * 1e3, "glyphs_per_step_all_gpus": c4[0],
+            "glyphs_per_s": c4[0] * k4 / el4, "mpixel_sdf_per_s": c4[1] * k4 / el4 * 1e-6,
+            "rank0_kernel_ms": ms4 / k4, "hbm_roofline_frac_all_gpus": c4[2] * k4 / el4 * 1e-9 / (HBM_PEAK_GBS * world),
+            "estimated_cost_max_over_mean": max(loads) / (sum(loads) / world),
+            "note": "longest-processing-time-first on estimated w*h*N per glyph, identical on every rank; no exchange in the timed "
+                    "step (resident raster of the rank's shard); the partial PBFs meet afterwards (dispatch.py: one all-to-all; "
+                    "in_library: shared memory)"}
+        db4.free()
+        del hb4, m4
+        # config 5: synthetic stress, rank r renders outlines [8192 r, 8192 (r + 1))
+        from versatiles_glyphs_rs_amd import synthetic as S5
+        b5 = S5.make_batch(rank * SYNTHETIC_PER_RANK, SYNTHETIC_PER_RANK)
+        db5 = ctx.upload(b5)
+        st5 = db5.stats()
+        k5 = 10
+        el5, ms5 = timed(db5, k5, 2)
+        c5 = all_sum([st5["n_glyphs"], st5["n_pixels"], st5["alg_bytes"]])
+        multi["synthetic_ranges"] = {
+            "config": f"BASELINE.json configs[4]: {c5[0]} of the 65 536 synthetic outlines (1024 segments, 70x70 px), "
+                      f"{SYNTHETIC_PER_RANK} per rank, rank r = index range [8192 r, 8192 (r + 1))",
+            "scaling": "weak", "steps": k5, "ms_per_step": el5 / k5 * 1e3, "glyphs_per_s": c5[0] * k5 / el5,
+            "mpixel_sdf_per_s": c5[1] * k5 / el5 * 1e-6, "rank0_kernel_ms": ms5 / k5,
+            "hbm_roofline_frac_all_gpus": c5[2] * k5 / el5 * 1e-9 / (HBM_PEAK_GBS * world)}
+        db5.free()
+        del b5
+    if world > 1 and not args.sharded and not synthetic and not args.no_configs:
+        # in-library form: ONE process (rank 0) drives all N devices through vg_renderer_new_multi while the other ranks
+        # wait (on the CPU: a gloo group, so that no collective kernel spins on their GPUs)
+        wait_group = dist.new_group(backend="gloo") if backend != "gloo" else None
+        if rank == 0:
+            try:
+                d4, p4 = workload_files("noto_all")
+                mm = vg.FontManager(True)
+                mm.add_font_with_name(d4, p4)
+                single = vg.Renderer.new_precise(local_rank)
+                lanes = vg.Renderer.new_multi([0] * world if os.environ.get("VG_SHARE_GPU") == "1" else list(range(world)))
+
+                def best_of(renderer, n=8):
+                    mm.render_glyphs(None, renderer)
+                    best, tm = None, None
+                    for _ in range(n):
+                        t0 = time.perf_counter()
+                        mm.render_glyphs(None, renderer)
+                        dt = time.perf_counter() - t0
+                        if best is None or dt < best:
+                            best, tm = dt, mm.timings()
+                    return best, tm
+                b1, t1 = best_of(single)
+                bn, tn = best_of(lanes)
+                multi["in_library"] = {
+                    "note": "fonts -> PBF bytes (PCIe inclusive, native NULL sink) of Noto Sans all languages by ONE process: "
+                            "Renderer.new_multi(devices 0..N-1) deals the glyph shards to N device lanes (one host thread each), "
+                            "partial PBFs merge in shared memory, counters reduced by vgsdf_reduce_counters (RCCL)",
+                    "devices": world, "seconds": bn, "glyphs_per_s": tn["glyphs"] / bn, "one_device_seconds": b1,
+                    "one_device_glyphs_per_s": t1["glyphs"] / b1, "reduced_counters": list(mm.reduced_counters()),
+                    "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
+                lanes.close(); single.close()
+            except Exception as e:  # noqa: BLE001  (the line must still be printed)
+                multi["in_library"] = {"error": f"{type(e).__name__}: {e}"}
+        dist.barrier(group=wait_group) if wait_group is not None else dist.barrier()
 
     if rank != 0:
         if dist is not None:
@@ -249,7 +351,6 @@ def main():
         "unit": "glyphs/s",
         "n_gpus": world,
         "steps": steps,
-        "steps_requested": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
@@ -310,7 +411,12 @@ def main():
                     "rate a brute-force evaluation would need",
         },
         "host_stage_s": host_s,
+        "steady": {"steps": k_long, "ms_per_step": steady_elapsed / k_long * 1e3, "glyphs_per_s": counters[1] * k_long / steady_elapsed,
+                   "kernel_ms_avg": steady_ms / k_long,
+                   "note": f"the same measurement over a region of >= {args.min_ms:g} ms, run BEFORE the headline's warm-up + K steps (it brings "
+                           "the GPU to its sustained clocks; reported beside the headline, never as `value`)"},
     }
+    out.update(multi)
     if shard_info:
         out["config"]["shard"] = shard_info
 
@@ -325,12 +431,12 @@ def main():
             db.launch(); d2.launch()
         ctx.sync(); c2.sync()
         t2 = time.perf_counter()
-        for i in range(steps):
+        for i in range(k_long):
             (db if i % 2 == 0 else d2).launch()
         ctx.sync(); c2.sync()
         e2 = time.perf_counter() - t2
         out["two_in_flight"] = {
-            "ms_per_step": e2 / steps * 1e3, "glyphs_per_s": st["n_glyphs"] * steps / e2, "steps": steps,
+            "ms_per_step": e2 / k_long * 1e3, "glyphs_per_s": st["n_glyphs"] * k_long / e2, "steps": k_long,
             "note": "the timed steps launched alternately on two contexts (two HIP streams, each with its own resident copy "
                     "of the batch and its own output); wall clock around launches + both synchronisations",
         }
@@ -428,8 +534,9 @@ def main():
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         tm = many.timings()
-        out["e2e"]["all_21_fixture_fonts_as_separate_fonts"] = {"glyphs_per_s": tm["glyphs"] / best, "seconds": best,
-                                                                 "glyphs": tm["glyphs"], "pbf_bytes": tm["pbf_bytes"]}
+        out["e2e"]["all_21_fixture_fonts_as_separate_fonts"] = {
+            "glyphs_per_s": tm["glyphs"] / best, "seconds": best, "glyphs": tm["glyphs"], "pbf_bytes": tm["pbf_bytes"],
+            "phases_s_last_run": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s", "total_s")}}
         if not args.no_cpu_baseline:
             c = cpu_e2e(paths, fid)
             out["e2e"]["cpu_port"] = c
@@ -446,7 +553,7 @@ def main():
             f2 = m2.add_font_with_name(d2, p2)
             hb2 = m2.build_batch(f2)
             db2 = ctx.upload(hb2.batch)
-            k2, _ = time_resident(ctx, db2, 20, 5, args.min_ms)
+            k2 = max(20, steps_for(ctx, db2, 5, args.min_ms))
             ms2 = db2.time(k2) / k2
             st2 = db2.stats()
             ent = {"workload": f"{wl}: {d2}, {len(p2)} file(s), all BMP code points", "glyphs": st2["n_glyphs"],
@@ -460,6 +567,33 @@ def main():
                 if not args.no_cpu_baseline and wl != "noto_all":  # (the 20-file CPU pass takes several seconds)
                     ent["e2e_cpu_port_glyphs_per_s"] = cpu_e2e(p2, f2)["glyphs_per_s"]
             out["configs"].append(ent)
+        # config 5 at one rank's size: outlines [0, 8192) of the 65 536 ("where the roofline is measured")
+        from versatiles_glyphs_rs_amd import synthetic as S
+        bs = S.make_batch(0, SYNTHETIC_PER_RANK)
+        dbs = ctx.upload(bs)
+        sts = dbs.stats()
+        for _ in range(3):
+            dbs.launch()
+        ctx.sync()
+        ks = 20
+        mss = dbs.time(ks) / ks
+        ent = {"workload": f"synthetic: outlines [0, {SYNTHETIC_PER_RANK}) of BASELINE.json configs[4] (1024 segments, 70x70 px each)",
+               "glyphs": sts["n_glyphs"], "segments": sts["n_segments"], "pixels": sts["n_pixels"], "steps": ks, "kernel_ms": mss,
+               "glyphs_per_s": sts["n_glyphs"] / (mss * 1e-3), "mpixel_sdf_per_s": sts["n_pixels"] / (mss * 1e-3) * 1e-6,
+               "roofline_frac_hbm": sts["alg_bytes"] / (mss * 1e-3) * 1e-9 / HBM_PEAK_GBS,
+               "brute_pairs_per_s": sts["n_pairs"] / (mss * 1e-3)}
+        pm = pmc_entry("synthetic", args.variant)
+        if pm:
+            ent["valu"] = {k: pm.get(k) for k in ("valu_insts_per_wave", "valu_busy_frac", "valu_cycles_per_inst", "kernel_ms")}
+        if not args.no_cpu_baseline:  # bounded CPU leg: the first 64 outlines
+            from oracle import oracle as O
+            smp = S.make_batch(0, 64)
+            ref, secs = O.sdf_render_batch(smp, O.PRECISE, O.default_threads())
+            got = dbs.download()[:smp.out_bytes]
+            ent["parity"] = "bit-exact vs oracle on outlines [0, 64)" if (ref == got).all() else "MISMATCH vs oracle"
+            ent["cpu_port_glyphs_per_s"] = 64 / secs
+        dbs.free()
+        out["configs"].append(ent)
 
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -55,6 +55,19 @@ typedef int (*vg_write_cb)(void *user, const char *path, const uint8_t *data, si
 const char *vg_last_error(void);
 
 vg_renderer *vg_renderer_new(int mode, int device_ordinal);
+/* ONE process, n devices (the reference is one process with a rayon pool, src/font/manager.rs:81-125):
+ * a HIP renderer with one lane per entry of `devices` (own device contexts and streams each; an entry may repeat a
+ * device).  vg_manager_render_glyphs / _to with such a renderer deal every font's glyphs to the lanes by estimated
+ * cost (vg_manager_shard_glyphs' table), render each shard on its own host thread, and merge the partial PBFs of a
+ * block in this process's memory — there is no exchange step.  Output bytes equal a single-device run's.  The run
+ * counters {blocks, glyphs, pixels} are summed over the lanes with vgsdf_reduce_counters (RCCL all-reduce when the
+ * devices are distinct) and checked; vg_manager_reduced_counters returns them.  NULL + vg_last_error() on failure. */
+vg_renderer *vg_renderer_new_multi(const int *devices, int n);
+int vg_renderer_device_count(const vg_renderer *r);
+/* sum of the lanes' run counters as they stand (vgsdf_reduce_counters over the renderer's contexts) */
+int vg_renderer_reduce_counters(const vg_renderer *r, uint64_t counters[3]);
+void vg_renderer_add_counters(const vg_renderer *r, int lane, uint64_t blocks, uint64_t glyphs, uint64_t pixels);
+void vg_renderer_reset_counters(const vg_renderer *r);
 void vg_renderer_free(vg_renderer *r);
 
 vg_manager *vg_manager_new(int parallel);
@@ -117,7 +130,7 @@ int vg_manager_shard_glyphs(const vg_manager *m, const char *font_id, uint32_t w
 /* From now on every render / build_batch / record_outlines call of this manager sees only the glyphs
  * that rank `rank` of `world` owns; every block is still emitted and its PBF holds this rank's glyphs
  * only (a partial).  world <= 1 switches sharding off. */
-void vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world);
+int vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world); /* -1: rank >= world or world > 254 */
 /* Merges partial PBFs of ONE block (disjoint glyph subsets, same name and range) into the block's PBF:
  * glyphs in ascending id, byte for byte what a single process encodes.  Returns the needed size. */
 long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap);
@@ -125,6 +138,8 @@ long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_
 int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id, const uint32_t *starts, int n,
                              vg_write_cb cb, void *user);
 int vg_manager_timings(const vg_manager *m, vg_timings *out);
+/* {blocks, glyphs, pixels} of the last render with a multi-device renderer, as reduced over its lanes (zeros otherwise) */
+void vg_manager_reduced_counters(const vg_manager *m, uint64_t counters[3]);
 /* GlyphBlock::render for one block of one font -> PBF bytes; returns needed size */
 long vg_manager_render_block(vg_manager *m, vg_renderer *r, const char *font_id, uint32_t start, uint8_t *out,
                              size_t cap);

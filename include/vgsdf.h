@@ -187,6 +187,24 @@ int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_byt
 /* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */
 int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey);
 
+/*
+ * Multi-GPU: ONE process drives N devices, one context (+ its own host thread) per device; glyph batches
+ * are independent (renderer.rs:103 has no shared state), so results need no exchange and the only collective of the
+ * path is the sum of the run counters {blocks, glyphs, pixels} over the contexts.
+ *   vgsdf_add_counters    : the dispatcher credits a context with the work it rendered there
+ *   vgsdf_reduce_counters : counters[3] = sum over ctxs[0..n).  Contexts on n DISTINCT devices: an RCCL all-reduce
+ *                           (sum, 3 x u64) over a communicator of exactly those devices, on the contexts' streams; every
+ *                           rank's result is checked against the others.  RCCL is loaded at first use (dlopen of
+ *                           librccl.so.1: no link-time dependency, shared with a host that already mapped it); if it
+ *                           cannot be loaded the call fails with VGSDF_E_HIP.  Contexts that share a device (n lanes
+ *                           rehearsed on one GPU) cannot form a communicator and are summed on the host.
+ * Replaces nothing in the reference (single process, rayon threads: src/font/manager.rs:81-125 counts nothing); it is
+ * the north star's "RCCL only for the final block-count reduce".
+ */
+void vgsdf_add_counters(vgsdf_ctx *ctx, uint64_t blocks, uint64_t glyphs, uint64_t pixels);
+void vgsdf_reset_counters(vgsdf_ctx *ctx);
+int vgsdf_reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3]);
+
 /* Raw device pointer of the resident output bitmaps (for zero-copy consumers on the same
  * device, e.g. a torch tensor wrapping it); valid until vgsdf_batch_free. */
 void *vgsdf_batch_device_output(const vgsdf_dbatch *b);

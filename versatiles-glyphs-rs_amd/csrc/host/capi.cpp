@@ -70,7 +70,38 @@ vg_renderer *vg_renderer_new(int mode, int device)
 	}
 	return new vg_renderer{std::move(r)};
 }
+vg_renderer *vg_renderer_new_multi(const int *devices, int n)
+{
+	if (!devices || n <= 0) {
+		g_err = "vg_renderer_new_multi: no devices";
+		return nullptr;
+	}
+	std::string err;
+	auto r = vg::Renderer::new_multi(std::vector<int>(devices, devices + n), &err);
+	if (!r) {
+		g_err = err;
+		return nullptr;
+	}
+	return new vg_renderer{std::move(r)};
+}
+int vg_renderer_device_count(const vg_renderer *r) { return (int)r->r->n_devices(); }
+int vg_renderer_reduce_counters(const vg_renderer *r, uint64_t counters[3])
+{
+	try {
+		r->r->reduce_counters(counters);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+void vg_renderer_add_counters(const vg_renderer *r, int lane, uint64_t blocks, uint64_t glyphs, uint64_t pixels)
+{
+	if (lane >= 0 && (size_t)lane < r->r->n_devices())
+		r->r->device_lane((size_t)lane).add_counters(blocks, glyphs, pixels);
+}
+void vg_renderer_reset_counters(const vg_renderer *r) { r->r->reset_counters(); }
 void vg_renderer_free(vg_renderer *r) { delete r; }
+void vg_manager_reduced_counters(const vg_manager *m, uint64_t counters[3]) { std::memcpy(counters, m->m.last_reduced_counters(), 3 * sizeof(uint64_t)); }
 
 vg_manager *vg_manager_new(int parallel) { return new vg_manager(parallel != 0); }
 void vg_manager_free(vg_manager *m) { delete m; }
@@ -111,7 +142,15 @@ int vg_manager_shard_glyphs(const vg_manager *m, const char *font_id, uint32_t w
 	return 0;
 }
 
-void vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world) { m->m.set_glyph_shard(rank, world); }
+int vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world)
+{
+	try {
+		m->m.set_glyph_shard(rank, world);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
 
 long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap)
 {

@@ -167,8 +167,30 @@ std::vector<GlyphBlock> FontWrapper::get_blocks() const
 	return blocks;
 }
 
+FontManager::~FontManager() = default;
+
+FontManager::FontManager(const FontManager *parent, uint32_t rank, uint32_t world)
+    : parent_(parent), parallel_(parent->parallel_)
+{
+	shard_rank_ = rank;
+	shard_world_ = world;
+	device_front_end_ = parent->device_front_end_;
+	batch_blocks_ = parent->batch_blocks_;
+	batch_blocks_set_ = parent->batch_blocks_set_;
+}
+
+// a font changed: shard tables, the ranks' filtered block tables and the lanes that hold them are stale
+void FontManager::invalidate_shards()
+{
+	std::lock_guard<std::mutex> lock(shard_mu_);
+	shard_cache_.clear();
+	shard_blocks_.clear();
+	children_.clear();
+}
+
 bool FontManager::add_font_with_name(const std::string &name, const std::vector<std::string> &sources, std::string *err)
 {
+	invalidate_shards();
 	return fonts_[name_to_id(name)].add_paths(sources, err);
 }
 
@@ -177,6 +199,7 @@ bool FontManager::add_font_data(const std::string &name, std::vector<uint8_t> da
 	auto e = FontFileEntry::create(std::move(data), err);
 	if (!e)
 		return false;
+	invalidate_shards();
 	fonts_[name_to_id(name)].add_file(std::move(e));
 	return true;
 }
@@ -189,6 +212,7 @@ bool FontManager::add_path(const std::string &path, std::string *err)
 	auto e = FontFileEntry::create(std::move(data), err);
 	if (!e)
 		return false;
+	invalidate_shards();
 	fonts_[name_to_id(e->metadata().generate_name())].add_file(std::move(e));
 	return true;
 }
@@ -375,8 +399,8 @@ void FontManager::tessellate_and_pack(const std::vector<Todo> &tasks, size_t t0,
 bool FontManager::build_batch(const std::string &font_id, PackedBatch &out, std::vector<uint32_t> &ids,
                               uint32_t &n_jobs, std::string *err)
 {
-	auto it = fonts_.find(font_id);
-	if (it == fonts_.end()) {
+	auto it = fonts().find(font_id);
+	if (it == fonts().end()) {
 		if (err)
 			*err = "unknown font id " + font_id;
 		return false;
@@ -399,8 +423,8 @@ bool FontManager::build_batch(const std::string &font_id, PackedBatch &out, std:
 
 bool FontManager::record_outlines(const std::string &font_id, OutlineBatch &out, std::string *err) const
 {
-	auto it = fonts_.find(font_id);
-	if (it == fonts_.end()) {
+	auto it = fonts().find(font_id);
+	if (it == fonts().end()) {
 		if (err)
 			*err = "unknown font id " + font_id;
 		return false;
@@ -476,47 +500,94 @@ double estimate_cost(const vgsdf_outline_cmd *c, uint32_t n, double scale)
 
 } // namespace
 
-bool FontManager::shard_glyphs(const std::string &font_id, uint32_t world, GlyphShard &out, std::string *err) const
+namespace {
+
+// longest processing time first; ties by code point, so every rank computes the same assignment
+void assign_lpt(GlyphShard &out)
 {
-	auto it = fonts_.find(font_id);
-	if (it == fonts_.end() || world == 0 || world > 254) {
-		if (err)
-			*err = it == fonts_.end() ? "unknown font id " + font_id : "shard_glyphs: world must be 1..254";
-		return false;
-	}
-	out.world = world;
-	out.owner.assign(0x10000, 0xFF);
-	out.cost.assign(0x10000, 0.0);
-	out.load.assign(world, 0.0);
-	// costs from the recorded outlines of ALL glyphs (cheap: table walks, no flattening), first provider wins
-	OutlineBatch rec;
 	std::vector<std::pair<double, uint32_t>> order; // (cost, code point)
-	for (const GlyphBlock &b : it->second.blocks())
-		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
-			if (const FontFileEntry *f = b.glyphs[ci]) {
-				const uint32_t cp = b.start_index + ci;
-				rec.clear();
-				double c = 1.0;
-				if (Renderer::record(f->face(), cp, rec))
-					c = estimate_cost(rec.cmds.data(), (uint32_t)rec.cmds.size(), rec.scale[0]);
-				out.cost[cp] = c;
-				order.emplace_back(c, cp);
-			}
-	// longest processing time first; ties by code point, so every rank computes the same assignment
+	for (uint32_t cp = 0; cp < 0x10000; cp++)
+		if (out.cost[cp] > 0.0)
+			order.emplace_back(out.cost[cp], cp);
 	std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+	out.owner.assign(0x10000, 0xFF);
+	out.load.assign(out.world, 0.0);
 	for (const auto &e : order) {
 		uint32_t best = 0;
-		for (uint32_t r = 1; r < world; r++)
+		for (uint32_t r = 1; r < out.world; r++)
 			if (out.load[r] < out.load[best])
 				best = r;
 		out.owner[e.second] = (uint8_t)best;
 		out.load[best] += e.first;
 	}
+}
+
+// estimated costs of the mapped glyphs of one block (cheap: table walks, no flattening), first provider wins
+void block_costs(const GlyphBlock &b, OutlineBatch &rec, std::vector<double> &cost)
+{
+	for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+		if (const FontFileEntry *f = b.glyphs[ci]) {
+			const uint32_t cp = b.start_index + ci;
+			rec.clear();
+			double c = 1.0;
+			if (Renderer::record(f->face(), cp, rec))
+				c = estimate_cost(rec.cmds.data(), (uint32_t)rec.cmds.size(), rec.scale[0]);
+			cost[cp] = c; // >= 1 for every mapped code point
+		}
+}
+
+} // namespace
+
+bool FontManager::shard_glyphs(const std::string &font_id, uint32_t world, GlyphShard &out, std::string *err) const
+{
+	auto it = fonts().find(font_id);
+	if (it == fonts().end() || world == 0 || world > 254) {
+		if (err)
+			*err = it == fonts().end() ? "unknown font id " + font_id : "shard_glyphs: world must be 1..254";
+		return false;
+	}
+	out.world = world;
+	out.cost.assign(0x10000, 0.0);
+	OutlineBatch rec;
+	for (const GlyphBlock &b : it->second.blocks())
+		block_costs(b, rec, out.cost);
+	assign_lpt(out);
 	return true;
+}
+
+// The same table, kept per (font, world, number of files) and built with the blocks spread over the calling thread's
+// pool when there is one (a lane asks its parent; the parent fills the cache before it starts the lanes).
+const GlyphShard &FontManager::cached_shard(const std::string &font_id, const FontWrapper &font, uint32_t world) const
+{
+	if (parent_)
+		return parent_->cached_shard(font_id, font, world);
+	std::lock_guard<std::mutex> lock(shard_mu_);
+	ShardEntry &e = shard_cache_[font_id];
+	if (e.world == world && e.n_files == font.files().size() && !e.shard.owner.empty())
+		return e.shard;
+	if (world == 0 || world > 254)
+		throw std::runtime_error("glyph shard: world must be 1..254");
+	e.world = world;
+	e.n_files = font.files().size();
+	e.shard.world = world;
+	e.shard.cost.assign(0x10000, 0.0);
+	const std::vector<GlyphBlock> &blocks = font.blocks();
+	if (pool_ && pool_->size() > 1) {
+		std::vector<OutlineBatch> recs(pool_->size());
+		pool_->run(blocks.size(), [&](size_t i, unsigned wid) { block_costs(blocks[i], recs[wid], e.shard.cost); });
+	} else {
+		OutlineBatch rec;
+		for (const GlyphBlock &b : blocks)
+			block_costs(b, rec, e.shard.cost);
+	}
+	assign_lpt(e.shard);
+	return e.shard;
 }
 
 void FontManager::set_glyph_shard(uint32_t rank, uint32_t world)
 {
+	if (world > 254 || (world > 1 && rank >= world))
+		throw std::runtime_error("set_glyph_shard: need rank < world <= 254");
 	shard_rank_ = rank;
 	shard_world_ = world ? world : 1;
 	shard_blocks_.clear();
@@ -527,12 +598,9 @@ const std::vector<GlyphBlock> &FontManager::task_blocks(const std::string &font_
 	if (shard_world_ <= 1)
 		return font.blocks();
 	auto it = shard_blocks_.find(font_id);
-	if (it != shard_blocks_.end() && it->second.size() == font.blocks().size())
-		return it->second;
-	GlyphShard sh;
-	std::string err;
-	if (!shard_glyphs(font_id, shard_world_, sh, &err))
-		throw std::runtime_error(err);
+	if (it != shard_blocks_.end())
+		return it->second; // (every add_* clears this table: invalidate_shards)
+	const GlyphShard &sh = cached_shard(font_id, font, shard_world_);
 	std::vector<GlyphBlock> blocks = font.blocks(); // copy, then drop what other ranks own
 	for (GlyphBlock &b : blocks)
 		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
@@ -627,21 +695,131 @@ std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_
 
 void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 {
+	if (renderer.n_devices() > 1 && renderer.mode() == Renderer::Mode::Hip && !parent_) {
+		render_glyphs_multi(writer, renderer);
+		return;
+	}
 	// manager.rs:86-97: one task per (font, block); all 256 blocks per font
 	std::vector<Todo> tasks;
-	for (const auto &[name, font] : fonts_) {
+	for (const auto &[name, font] : fonts()) {
 		writer.write_directory(name + "/");
 		for (const GlyphBlock &b : task_blocks(name, font))
 			tasks.push_back(Todo{&name, b});
 	}
+	std::memset(reduced_, 0, sizeof reduced_);
 	run_tasks(tasks, writer, renderer);
+}
+
+namespace {
+// what a lane of render_glyphs_multi writes into: its partial PBFs, in task order
+struct CaptureWriter final : Writer {
+	std::vector<std::vector<uint8_t>> files;
+	void write_directory(const std::string &) override {}
+	void write_file(const std::string &, const std::vector<uint8_t> &data) override { files.push_back(data); }
+};
+} // namespace
+
+void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
+{
+	const double t_start = now_s();
+	const uint32_t world = (uint32_t)renderer.n_devices();
+	ThreadPool &tp = pool();
+	// lanes: one per device entry, each with its share of the host threads; kept between runs
+	if (children_.size() != world) {
+		children_.clear();
+		for (uint32_t r = 0; r < world; r++)
+			children_.emplace_back(new FontManager(this, r, world));
+	}
+	const unsigned per_lane = std::max(1u, worker_count() / world);
+	for (auto &c : children_) {
+		c->device_front_end_ = device_front_end_;
+		c->batch_blocks_ = batch_blocks_;
+		c->batch_blocks_set_ = batch_blocks_set_;
+		c->set_threads(per_lane);
+	}
+	// shard tables of every font, built on this manager's pool before the lanes start (they only read them)
+	for (const auto &[name, font] : fonts_)
+		(void)cached_shard(name, font, world);
+	const double t_sharded = now_s();
+
+	renderer.reset_counters();
+	std::vector<CaptureWriter> parts(world);
+	std::vector<std::exception_ptr> errors(world);
+	std::vector<std::thread> threads;
+	for (uint32_t r = 0; r < world; r++)
+		threads.emplace_back([&, r] {
+			try {
+				children_[r]->render_glyphs(parts[r], renderer.device_lane(r));
+			} catch (...) {
+				errors[r] = std::current_exception();
+			}
+		});
+	for (std::thread &t : threads)
+		t.join();
+	for (const std::exception_ptr &e : errors)
+		if (e)
+			std::rethrow_exception(e); // first error aborts (manager.rs:117-121)
+	const double t_rendered = now_s();
+
+	// merge: block b of every lane holds a disjoint subset of the block's glyphs
+	std::vector<const std::string *> names;
+	for (const auto &kv : fonts_)
+		names.push_back(&kv.first);
+	const size_t n_files = names.size() * (0x10000 / GLYPH_BLOCK_SIZE);
+	for (const CaptureWriter &p : parts)
+		if (p.files.size() != n_files)
+			throw std::runtime_error("render_glyphs: a device lane produced " + std::to_string(p.files.size()) + " files instead of " + std::to_string(n_files));
+	std::vector<std::vector<uint8_t>> merged(n_files);
+	tp.run(n_files, [&](size_t i, unsigned) {
+		std::vector<std::pair<const uint8_t *, size_t>> ps;
+		for (const CaptureWriter &p : parts)
+			ps.emplace_back(p.files[i].data(), p.files[i].size());
+		merged[i] = merge_pbf_partials(ps);
+	});
+	const double t_merged = now_s();
+	timings_ = RenderTimings{};
+	for (const std::string *name : names)
+		writer.write_directory(*name + "/");
+	for (size_t i = 0; i < n_files; i++) {
+		const uint32_t start = (uint32_t)(i % (0x10000 / GLYPH_BLOCK_SIZE)) * GLYPH_BLOCK_SIZE;
+		writer.write_file(*names[i / (0x10000 / GLYPH_BLOCK_SIZE)] + "/" + std::to_string(start) + "-" + std::to_string(start + GLYPH_BLOCK_SIZE - 1) + ".pbf",
+		                  merged[i]);
+		timings_.pbf_bytes += merged[i].size();
+	}
+	const double t_written = now_s();
+
+	// run counters: lane r is credited with its own glyphs and pixels and with the blocks it owns (block index mod N),
+	// the lanes' contexts sum them (RCCL when the devices are distinct) and the sum must be what this process knows
+	uint64_t want[3] = {n_files, 0, 0};
+	for (uint32_t r = 0; r < world; r++) {
+		const RenderTimings &ct = children_[r]->timings_;
+		renderer.device_lane(r).add_counters((n_files + world - 1 - r) / world, ct.glyphs, ct.pixels);
+		want[1] += ct.glyphs;
+		want[2] += ct.pixels;
+		timings_.tessellate_s = std::max(timings_.tessellate_s, ct.tessellate_s);
+		timings_.pack_s = std::max(timings_.pack_s, ct.pack_s);
+		timings_.device_s = std::max(timings_.device_s, ct.device_s);
+		timings_.encode_s = std::max(timings_.encode_s, ct.encode_s);
+		timings_.glyphs += ct.glyphs;
+		timings_.rasters += ct.rasters;
+		timings_.pixels += ct.pixels;
+		timings_.segments += ct.segments;
+	}
+	renderer.reduce_counters(reduced_);
+	if (std::memcmp(reduced_, want, sizeof want) != 0)
+		throw std::runtime_error("render_glyphs: the reduced run counters differ from the lanes' own");
+	timings_.blocks = n_files;
+	timings_.pack_s += t_sharded - t_start;              // (shard tables: first run of a font set only)
+	timings_.encode_s += t_merged - t_rendered;          // merge of the partials
+	timings_.write_s = t_written - t_merged;
+	timings_.total_s = now_s() - t_start;
 }
 
 void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const std::string &font_id,
                                 const std::vector<uint32_t> &block_starts)
 {
-	auto it = fonts_.find(font_id);
-	if (it == fonts_.end())
+	auto it = fonts().find(font_id);
+	if (it == fonts().end())
 		throw std::runtime_error("unknown font id " + font_id);
 	const std::vector<GlyphBlock> &blocks = task_blocks(it->first, it->second);
 	std::vector<Todo> tasks;

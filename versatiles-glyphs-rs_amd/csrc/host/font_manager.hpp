@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -123,6 +124,7 @@ struct RenderTimings {
 class FontManager {
 public:
 	explicit FontManager(bool parallel) : parallel_(parallel) {} // manager.rs:28-33
+	~FontManager();
 
 	// manager.rs:66-75
 	bool add_font_with_name(const std::string &name, const std::vector<std::string> &sources, std::string *err);
@@ -168,8 +170,11 @@ public:
 	// first provider wins): what vgsdf_outlines_prepare is fed.
 	bool record_outlines(const std::string &font_id, OutlineBatch &out, std::string *err) const;
 
-	const std::map<std::string, FontWrapper> &fonts() const { return fonts_; }
+	const std::map<std::string, FontWrapper> &fonts() const { return parent_ ? parent_->fonts_ : fonts_; }
 	const RenderTimings &last_timings() const { return timings_; }
+	// {blocks, glyphs, pixels} of the last multi-device render_glyphs, as vgsdf_reduce_counters summed them over the
+	// device lanes (all zero after a single-device run: there is nothing to reduce)
+	const uint64_t *last_reduced_counters() const { return reduced_; }
 	void set_threads(unsigned n) { threads_ = n; }
 	void set_batch_blocks(unsigned n)
 	{
@@ -208,6 +213,26 @@ private:
 		OutlineBatch olocal;
 		char pad[128];
 	};
+	// One process, N devices (renderer.n_devices() > 1): the glyphs of every font are dealt to the device lanes by
+	// estimated cost (shard_glyphs), lane i renders its shard on its own host thread with its own pool, buffers and
+	// device contexts, the partial PBFs of a block land side by side in this process's memory and are merged
+	// (merge_pbf_partials) — no exchange step; the run counters are summed over the lanes by vgsdf_reduce_counters.
+	void render_glyphs_multi(Writer &writer, const Renderer &renderer);
+	// a lane of render_glyphs_multi: shares the parent's fonts, renders the glyphs rank `rank` of `world` owns
+	FontManager(const FontManager *parent, uint32_t rank, uint32_t world);
+	const FontManager *parent_ = nullptr;
+	std::vector<std::unique_ptr<FontManager>> children_; // lanes, kept between runs (their buffers are grow-only)
+	// shard tables, built once per (font, world, number of files) — on the pool — and shared with the lanes
+	struct ShardEntry {
+		uint32_t world = 0;
+		size_t n_files = 0;
+		GlyphShard shard;
+	};
+	mutable std::map<std::string, ShardEntry> shard_cache_;
+	mutable std::mutex shard_mu_;
+	const GlyphShard &cached_shard(const std::string &font_id, const FontWrapper &font, uint32_t world) const;
+	void invalidate_shards();
+	uint64_t reduced_[3] = {0, 0, 0};
 	void run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
 	void run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
 	// tessellate tasks [t0, t1) on the pool and pack them (task order, ascending id) into `out`

@@ -145,6 +145,55 @@ std::shared_ptr<Renderer> Renderer::new_precise(int device, std::string *err)
 	return r;
 }
 
+std::shared_ptr<Renderer> Renderer::new_multi(const std::vector<int> &devices, std::string *err)
+{
+	if (devices.empty() || devices.size() > 254) {
+		if (err)
+			*err = "Renderer::new_multi: 1 .. 254 devices";
+		return nullptr;
+	}
+	std::shared_ptr<Renderer> r = new_precise(devices[0], err);
+	if (!r)
+		return nullptr;
+	for (size_t i = 1; i < devices.size(); i++) {
+		std::shared_ptr<Renderer> p = new_precise(devices[i], err);
+		if (!p)
+			return nullptr;
+		r->peers_.push_back(std::move(p));
+	}
+	return r;
+}
+
+void Renderer::add_counters(uint64_t blocks, uint64_t glyphs, uint64_t pixels) const
+{
+	if (mode_ != Mode::Hip)
+		return;
+	std::lock_guard<std::mutex> lock(mu_);
+	vgsdf_add_counters(ctx_, blocks, glyphs, pixels);
+}
+
+void Renderer::reset_counters() const
+{
+	for (size_t i = 0; i < n_devices(); i++) {
+		const Renderer &l = device_lane(i);
+		if (l.mode_ == Mode::Hip) {
+			std::lock_guard<std::mutex> lock(l.mu_);
+			vgsdf_reset_counters(l.ctx_);
+		}
+	}
+}
+
+void Renderer::reduce_counters(uint64_t out[3]) const
+{
+	if (mode_ != Mode::Hip)
+		throw std::runtime_error("reduce_counters needs the HIP renderer");
+	std::vector<vgsdf_ctx *> ctxs;
+	for (size_t i = 0; i < n_devices(); i++)
+		ctxs.push_back(device_lane(i).ctx_);
+	if (vgsdf_reduce_counters(ctxs.data(), (int)ctxs.size(), out) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_reduce_counters: ") + vgsdf_last_error(ctx_));
+}
+
 Renderer::~Renderer()
 {
 	if (ctx2_)

@@ -255,6 +255,18 @@ public:
 	static std::shared_ptr<Renderer> create(bool dummy, int device = 0, std::string *err = nullptr);
 	static std::shared_ptr<Renderer> new_precise(int device = 0, std::string *err = nullptr); // HIP back-end
 	static std::shared_ptr<Renderer> new_dummy();
+	// ONE process, N devices (the reference is one process too, manager.rs:81-125): a HIP renderer on
+	// devices[0] plus one peer per further entry, each with its own device contexts and streams.  An entry may repeat a
+	// device (N lanes rehearsed on one GPU).  FontManager::render_glyphs deals a font's glyph shards to the lanes, one host
+	// thread each; every single-renderer call on the object goes to devices[0].
+	static std::shared_ptr<Renderer> new_multi(const std::vector<int> &devices, std::string *err = nullptr);
+	size_t n_devices() const { return 1 + peers_.size(); }
+	const Renderer &device_lane(size_t i) const { return i == 0 ? *this : *peers_[i - 1]; }
+	// run counters {blocks, glyphs, pixels}: credited to the lane that did the work, summed over the lanes by
+	// vgsdf_reduce_counters (an RCCL all-reduce when the lanes sit on distinct devices).  Hip mode only.
+	void add_counters(uint64_t blocks, uint64_t glyphs, uint64_t pixels) const;
+	void reset_counters() const;
+	void reduce_counters(uint64_t out[3]) const;
 	~Renderer();
 
 	Mode mode() const { return mode_; }
@@ -301,6 +313,7 @@ private:
 	mutable vgsdf_ctx *ctx2_ = nullptr; // lane 1 of the two-deep pipeline (created on first use)
 	mutable std::mutex lane_mu_[2];     // held from submit_outlines to wait_outlines
 	vgsdf_ctx *lane_ctx(int lane) const;
+	std::vector<std::shared_ptr<Renderer>> peers_; // device lanes 1 .. N-1 of a multi-device renderer
 };
 
 } // namespace vg

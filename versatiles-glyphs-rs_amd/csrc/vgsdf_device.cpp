@@ -3,11 +3,14 @@
 // product: if HIP is unusable every entry point reports VGSDF_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -67,6 +70,11 @@ struct vgsdf_ctx {
 	void *d_scratch = nullptr, *h_scratch = nullptr;
 	size_t d_scratch_bytes = 0, h_scratch_bytes = 0;
 	struct FrontEnd *fe = nullptr; // device outline front-end state (lazy)
+	// run counters {blocks, glyphs, pixels} of the work this context did (vgsdf_add_counters), summed over the
+	// contexts of a run by vgsdf_reduce_counters; d_counters: 24 bytes on the device for the collective
+	uint64_t counters[3] = {0, 0, 0};
+	uint64_t *d_counters = nullptr;
+	void *comm = nullptr; // ncclComm_t of the communicator this context last reduced in (owned by the cache below)
 };
 
 struct vgsdf_dbatch {
@@ -229,6 +237,8 @@ void vgsdf_destroy(vgsdf_ctx *ctx)
 		ctx->fe->release_all();
 		delete ctx->fe;
 	}
+	if (ctx->d_counters)
+		(void)hipFree(ctx->d_counters);
 	if (ctx->d_scratch)
 		(void)hipFree(ctx->d_scratch);
 	if (ctx->h_scratch)
@@ -1298,6 +1308,164 @@ int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, doubl
 		ex[i] = rec[4 * i + 2];
 		ey[i] = rec[4 * i + 3];
 	}
+	return VGSDF_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Run counters and their reduction over the contexts of a run (the one collective of the path —
+// results need no exchange, every glyph is independent).  One process drives N devices, one context each; with
+// distinct devices the sum is an RCCL all-reduce of 3 x u64 over a communicator of those devices (ncclCommInitAll;
+// the library is loaded at first use with dlopen, so libvgsdf.so carries no link-time dependency on RCCL and shares
+// the copy a host such as PyTorch has already mapped).  Contexts that share a device (a rehearsal of N lanes on one
+// GPU) cannot form a communicator — RCCL refuses two ranks on one device — and are summed on the host.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+	void *lib = nullptr;
+	int (*CommInitAll)(void **, int, const int *) = nullptr;
+	int (*CommDestroy)(void *) = nullptr;
+	int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	const char *(*GetErrorString)(int) = nullptr;
+	std::string err;
+	bool load()
+	{
+		if (lib)
+			return true;
+		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (lib)
+				break;
+		}
+		if (!lib) {
+			err = std::string("RCCL is not loadable (") + (dlerror() ? dlerror() : "librccl.so.1") + ")";
+			return false;
+		}
+		auto sym = [&](const char *n) { return dlsym(lib, n); };
+		CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+		CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+		AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+		GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+		GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+		GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+		if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
+			err = "RCCL: a collective entry point is missing from the library";
+			dlclose(lib);
+			lib = nullptr;
+			return false;
+		}
+		return true;
+	}
+};
+Rccl g_rccl;
+// communicators by device list (creating one costs ~100 ms): kept for the life of the process
+struct CommSet {
+	std::vector<int> devices;
+	std::vector<void *> comms;
+};
+std::vector<CommSet> g_comm_sets;
+std::mutex g_comm_mu;
+constexpr int kNcclUint64 = 5, kNcclSum = 0; // rccl.h: ncclDataType_t / ncclRedOp_t
+} // namespace
+
+void vgsdf_add_counters(vgsdf_ctx *ctx, uint64_t blocks, uint64_t glyphs, uint64_t pixels)
+{
+	if (!ctx)
+		return;
+	ctx->counters[0] += blocks;
+	ctx->counters[1] += glyphs;
+	ctx->counters[2] += pixels;
+}
+
+void vgsdf_reset_counters(vgsdf_ctx *ctx)
+{
+	if (ctx)
+		ctx->counters[0] = ctx->counters[1] = ctx->counters[2] = 0;
+}
+
+int vgsdf_reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3])
+{
+	if (!ctxs || n <= 0 || !counters) {
+		if (ctxs && n > 0 && ctxs[0])
+			ctxs[0]->err = "vgsdf_reduce_counters: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	for (int i = 0; i < n; i++)
+		if (!ctxs[i])
+			return VGSDF_E_ARG;
+	vgsdf_ctx *c0 = ctxs[0];
+	std::vector<int> devs((size_t)n);
+	bool distinct = true;
+	for (int i = 0; i < n; i++) {
+		devs[(size_t)i] = ctxs[i]->device;
+		for (int j = 0; j < i; j++)
+			distinct = distinct && ctxs[j]->device != ctxs[i]->device;
+	}
+	uint64_t host_sum[3] = {0, 0, 0};
+	for (int i = 0; i < n; i++)
+		for (int k = 0; k < 3; k++)
+			host_sum[k] += ctxs[i]->counters[k];
+	if (!distinct) { // lanes sharing a device: no communicator possible (see above)
+		std::memcpy(counters, host_sum, sizeof host_sum);
+		return VGSDF_OK;
+	}
+	std::lock_guard<std::mutex> lock(g_comm_mu);
+	if (!g_rccl.load()) {
+		c0->err = "vgsdf_reduce_counters: " + g_rccl.err;
+		return VGSDF_E_HIP;
+	}
+	CommSet *set = nullptr;
+	for (CommSet &cs : g_comm_sets)
+		if (cs.devices == devs)
+			set = &cs;
+	if (!set) {
+		CommSet cs;
+		cs.devices = devs;
+		cs.comms.assign((size_t)n, nullptr);
+		const int rc = g_rccl.CommInitAll(cs.comms.data(), n, devs.data());
+		if (rc != 0) {
+			c0->err = std::string("vgsdf_reduce_counters: ncclCommInitAll: ") + g_rccl.GetErrorString(rc);
+			return VGSDF_E_HIP;
+		}
+		g_comm_sets.push_back(std::move(cs));
+		set = &g_comm_sets.back();
+	}
+	for (int i = 0; i < n; i++) {
+		vgsdf_ctx *c = ctxs[i];
+		HIP_TRY(c0, hipSetDevice(c->device));
+		if (!c->d_counters)
+			HIP_TRY(c0, hipMalloc((void **)&c->d_counters, 3 * sizeof(uint64_t)));
+		HIP_TRY(c0, hipMemcpyAsync(c->d_counters, c->counters, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+		c->comm = set->comms[(size_t)i];
+	}
+	int rc = g_rccl.GroupStart();
+	for (int i = 0; i < n && rc == 0; i++) {
+		vgsdf_ctx *c = ctxs[i];
+		(void)hipSetDevice(c->device);
+		rc = g_rccl.AllReduce(c->d_counters, c->d_counters, 3, kNcclUint64, kNcclSum, c->comm, c->stream);
+	}
+	const int rc_end = g_rccl.GroupEnd();
+	if (rc == 0)
+		rc = rc_end;
+	if (rc != 0) {
+		c0->err = std::string("vgsdf_reduce_counters: RCCL all-reduce: ") + g_rccl.GetErrorString(rc);
+		return VGSDF_E_HIP;
+	}
+	// every rank holds the sum; all of them are read back and must agree with each other and with the host's own sum
+	for (int i = 0; i < n; i++) {
+		vgsdf_ctx *c = ctxs[i];
+		uint64_t got[3] = {0, 0, 0};
+		HIP_TRY(c0, hipSetDevice(c->device));
+		HIP_TRY(c0, hipMemcpyAsync(got, c->d_counters, sizeof got, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c0, hipStreamSynchronize(c->stream));
+		if (std::memcmp(got, host_sum, sizeof got) != 0) {
+			c0->err = "vgsdf_reduce_counters: the all-reduced counters of rank " + std::to_string(i) + " differ from the sum of the ranks' counters";
+			return VGSDF_E_HIP;
+		}
+	}
+	std::memcpy(counters, host_sum, sizeof host_sum);
 	return VGSDF_OK;
 }
 

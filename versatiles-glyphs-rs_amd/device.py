@@ -47,6 +47,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
     "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
+    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters",
 ]
 
 _lib = None
@@ -90,12 +91,28 @@ def load_library():
         L.vgsdf_outlines_wait.argtypes = [vp, vp, vp, vp, vp]
         L.vgsdf_outlines_submit_packed.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.vgsdf_add_counters.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.vgsdf_add_counters.restype = None
+        L.vgsdf_reset_counters.argtypes = [vp]
+        L.vgsdf_reset_counters.restype = None
+        L.vgsdf_reduce_counters.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
 
 def device_count() -> int:
     return load_library().vgsdf_device_count()
+
+
+def reduce_counters(contexts):
+    """vgsdf_reduce_counters: (blocks, glyphs, pixels) summed over the contexts' run counters — an RCCL all-reduce when
+    the contexts sit on distinct devices (a single context included: a communicator of one rank)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    out = (C.c_uint64 * 3)()
+    rc = load_library().vgsdf_reduce_counters(arr, len(contexts), out)
+    if rc != 0:
+        raise VgsdfError(rc, (load_library().vgsdf_last_error(contexts[0]._h) or b"").decode())
+    return tuple(int(v) for v in out)
 
 
 @dataclass
@@ -210,6 +227,12 @@ class SdfContext:
 
     def set_variant(self, v: int):
         self._check(load_library().vgsdf_set_variant(self._h, v))
+
+    def add_counters(self, blocks: int, glyphs: int, pixels: int):
+        load_library().vgsdf_add_counters(self._h, blocks, glyphs, pixels)
+
+    def reset_counters(self):
+        load_library().vgsdf_reset_counters(self._h)
 
     def render_batch(self, batch: Batch) -> np.ndarray:
         out = np.empty(batch.out_bytes, dtype=np.uint8)

@@ -1,9 +1,11 @@
-"""Multi-GPU sharding of the (font, block) task list — one process per GPU.
+"""One process per GPU (torchrun): sharding of the (font, block) task list, or of a font's glyphs, over the ranks.
 
-The reference's unit of parallel work is the 256-code-point GlyphBlock
-(/root/reference/src/font/manager.rs:86-97,117-121); blocks are independent, so ranks take
-disjoint subsets and no rendered data is ever exchanged.  The only collective is the final
-3 x u64 {blocks, glyphs, pixels} counter all-reduce (RCCL under backend "nccl", gloo on CPU).
+The library itself drives N devices from ONE process (Renderer.new_multi; csrc/host/font_manager.cpp,
+render_glyphs_multi) — that is the form a host application links.  This module is the launcher-side plumbing for the
+one-process-per-GPU form the benchmark driver uses: the reference's unit of parallel work is the 256-code-point
+GlyphBlock (/root/reference/src/font/manager.rs:86-97,117-121); whole blocks need no exchange at all
+(render_sharded), glyph-level shards need one all-to-all of partial PBFs to the block owners
+(render_sharded_glyphs); the counters {blocks, glyphs, pixels} are all-reduced (RCCL under backend "nccl", gloo on CPU).
 """
 from __future__ import annotations
 
@@ -39,8 +41,7 @@ def render_sharded(mgr, renderer, font_id: str, writer, rank: int, world: int, d
     device for the counter tensor ("cuda" with nccl, "cpu" with gloo)."""
     shards = shard_blocks(mgr.block_counts(font_id), world)
     mine = shards[rank]
-    if rank == 0:
-        writer.write_directory(font_id + "/")
+    writer.write_directory(font_id + "/")  # on every rank: each writes its own blocks, possibly under its own root
     mgr.render_glyphs(writer, renderer, font_id=font_id, block_starts=mine)
     t = mgr.timings()
     counters = [t["blocks"], t["glyphs"], t["pixels"]]
@@ -52,29 +53,31 @@ def render_sharded(mgr, renderer, font_id: str, writer, rank: int, world: int, d
     return {"blocks": counters[0], "glyphs": counters[1], "pixels": counters[2], "my_blocks": mine}
 
 
-def _pack_partials(files, font_id):
-    """this rank's 256 partial PBFs of a font -> one uint8 buffer: 257 x u64 offsets, then the bytes (block order)"""
-    names = [f"{font_id}/{b * 256}-{b * 256 + 255}.pbf" for b in range(256)]
-    blobs = [files[n] for n in names]
-    off = np.zeros(257, dtype=np.uint64)
-    off[1:] = np.cumsum([len(b) for b in blobs])
-    return np.concatenate([off.view(np.uint8), np.frombuffer(b"".join(blobs), dtype=np.uint8)])
+def _pack_for(files, font_id, dest: int, world: int) -> np.ndarray:
+    """this rank's partial PBFs of the blocks rank `dest` owns (block b belongs to rank b % world), as one uint8
+    buffer: u64 lengths of those blocks, then their bytes, in block order"""
+    blobs = [files[f"{font_id}/{b * 256}-{b * 256 + 255}.pbf"] for b in range(dest, 256, world)]
+    lens = np.array([len(b) for b in blobs], dtype=np.uint64)
+    return np.concatenate([lens.view(np.uint8), np.frombuffer(b"".join(blobs), dtype=np.uint8)])
 
 
-def _unpack_partial(buf: np.ndarray, block: int) -> bytes:
-    off = buf[: 257 * 8].view(np.uint64)
-    return buf[257 * 8 + int(off[block]): 257 * 8 + int(off[block + 1])].tobytes()
+def _unpack_from(buf: np.ndarray, n_blocks: int):
+    lens = buf[: 8 * n_blocks].view(np.uint64)
+    off = 8 * n_blocks + np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return [buf[off[i]: off[i + 1]].tobytes() for i in range(n_blocks)]
 
 
 def render_sharded_glyphs(mgr, renderer, font_id: str, writer, rank: int, world: int, dist=None, device=None):
-    """Glyph-level sharding of one font over `world` ranks (the reference's unit is the
-    (font, block) task, manager.rs:86-97, but 45 unequal non-empty blocks do not balance over 8 GPUs).
+    """One process per GPU: glyph-level sharding of one font over `world` ranks (the reference's unit is
+    the (font, block) task, manager.rs:86-97, but 45 unequal non-empty blocks do not balance over 8 GPUs).  (ONE process
+    driving N devices needs none of this: Renderer.new_multi + FontManager.render_glyphs merge in shared memory.)
 
     1. every rank derives the same longest-processing-time-first assignment of glyphs to ranks from the
        font alone (FontManager.shard_glyphs: no communication);
     2. it renders its glyphs of EVERY block -> 256 partial PBFs;
-    3. the partials travel to the block owners (block b belongs to rank b % world): one all-gather of the
-       packed partials (RCCL under backend "nccl", gloo on the CPU) — the path's one real exchange step;
+    3. the partials travel to the block owners (block b belongs to rank b % world): ONE all-to-all in which rank r sends
+       rank d only the partials of d's blocks (RCCL under backend "nccl", gloo on the CPU) — total traffic = the
+       partials once, instead of every rank receiving every partial;
     4. every rank merges and writes its own blocks (pbf_merge: glyph messages as they are, ascending id), so
        the union of the ranks' files equals the single-process output byte for byte.
     Returns the world-wide counters."""
@@ -86,29 +89,31 @@ def render_sharded_glyphs(mgr, renderer, font_id: str, writer, rank: int, world:
         t = mgr.timings()
     finally:
         mgr.set_glyph_shard(0, 1)
-    mine = _pack_partials(local.files, font_id)
+    my_blocks = list(range(rank, 256, world))
     if dist is not None and world > 1:
         import torch
         dev = device or "cpu"
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        sizes[rank] = mine.size
-        dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
-        cap = int(sizes.max().item())
-        send = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        send[: mine.size] = torch.from_numpy(mine.copy()).to(dev)
-        recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(recv, send)
-        recv = recv.cpu().numpy().reshape(world, cap)
-        parts = [recv[r, : int(sizes[r].item())] for r in range(world)]
+        outgoing = [_pack_for(local.files, font_id, d, world) for d in range(world)]
+        in_sizes = torch.tensor([o.size for o in outgoing], dtype=torch.int64, device=dev)
+        out_sizes = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(out_sizes, in_sizes)  # how much every peer is about to send me
+        out_split = [int(v) for v in out_sizes.tolist()]
+        send = torch.from_numpy(np.concatenate(outgoing)).to(dev)
+        recv = torch.empty(sum(out_split), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, out_split, [o.size for o in outgoing])
+        recv = recv.cpu().numpy()
+        offs = np.concatenate([[0], np.cumsum(out_split)])
+        per_rank = [_unpack_from(recv[offs[r]: offs[r + 1]], len(my_blocks)) for r in range(world)]
         c = torch.tensor([t["glyphs"], t["pixels"]], dtype=torch.int64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         glyphs, pixels = (int(v) for v in c.tolist())
     else:
         assert world == 1, "world > 1 needs an initialised torch.distributed module"
-        parts, glyphs, pixels = [mine], t["glyphs"], t["pixels"]
-    if rank == 0:
-        writer.write_directory(font_id + "/")
-    my_blocks = list(range(rank, 256, world))
-    for b in my_blocks:
-        writer.write_file(f"{font_id}/{b * 256}-{b * 256 + 255}.pbf", pbf_merge([_unpack_partial(p, b) for p in parts]))
+        per_rank = [_unpack_from(_pack_for(local.files, font_id, 0, 1), 256)]
+        glyphs, pixels = t["glyphs"], t["pixels"]
+    # every rank makes sure the font's directory exists where IT writes (idempotent for a directory sink; a tar per rank
+    # needs its own entry anyway)
+    writer.write_directory(font_id + "/")
+    for i, b in enumerate(my_blocks):
+        writer.write_file(f"{font_id}/{b * 256}-{b * 256 + 255}.pbf", pbf_merge([p[i] for p in per_rank]))
     return {"blocks": 256, "glyphs": glyphs, "pixels": pixels, "my_blocks": [b * 256 for b in my_blocks]}

@@ -46,6 +46,8 @@ VGFONT_SYMBOLS = [
     "vg_writer_new_tar_fd", "vg_writer_new_dir", "vg_writer_write_file", "vg_writer_write_directory", "vg_writer_finish",
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
     "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
+    "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_add_counters",
+    "vg_renderer_reset_counters", "vg_manager_reduced_counters",
 ]
 
 _bound = False
@@ -93,7 +95,16 @@ def _L():
         L.vg_manager_scan.argtypes = [vp, C.c_char_p]
         L.vg_manager_shard_glyphs.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp]
         L.vg_manager_set_glyph_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
-        L.vg_manager_set_glyph_shard.restype = None
+        L.vg_renderer_new_multi.restype = vp
+        L.vg_renderer_new_multi.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.vg_renderer_device_count.argtypes = [vp]
+        L.vg_renderer_reduce_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.vg_renderer_add_counters.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.vg_renderer_add_counters.restype = None
+        L.vg_renderer_reset_counters.argtypes = [vp]
+        L.vg_renderer_reset_counters.restype = None
+        L.vg_manager_reduced_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.vg_manager_reduced_counters.restype = None
         L.vg_pbf_merge.restype = C.c_long
         L.vg_pbf_merge.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t]
         for f in (L.vg_manager_font_ids, L.vg_manager_index_json, L.vg_manager_families_json):
@@ -155,6 +166,33 @@ class Renderer:
     @classmethod
     def new_dummy(cls):
         return cls(_L().vg_renderer_new(MODE_DUMMY, 0), MODE_DUMMY)
+
+    @classmethod
+    def new_multi(cls, devices):
+        """ONE process, one lane per entry of `devices` (an entry may repeat a device): FontManager.render_glyphs deals a
+        font's glyphs to the lanes and merges their partial PBFs in this process (include/vgfont.h)."""
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = _L().vg_renderer_new_multi(devs, len(devices))
+        if not h:
+            raise VgsdfError(-2, _err())
+        return cls(h, MODE_HIP)
+
+    @property
+    def n_devices(self) -> int:
+        return int(_L().vg_renderer_device_count(self._h))
+
+    def add_counters(self, lane: int, blocks: int, glyphs: int, pixels: int):
+        _L().vg_renderer_add_counters(self._h, lane, blocks, glyphs, pixels)
+
+    def reset_counters(self):
+        _L().vg_renderer_reset_counters(self._h)
+
+    def reduce_counters(self):
+        """(blocks, glyphs, pixels) summed over the lanes: vgsdf_reduce_counters (RCCL when the devices are distinct)"""
+        out = (C.c_uint64 * 3)()
+        if _L().vg_renderer_reduce_counters(self._h, out) != 0:
+            raise RuntimeError(_err())
+        return tuple(int(v) for v in out)
 
     def render_glyph(self, manager: "FontManager", font_id: str, index: int, file_index: int = 0):
         """Renderer::render_glyph(&face, index) -> PbfGlyph | None"""
@@ -308,7 +346,14 @@ class FontManager:
 
     def set_glyph_shard(self, rank: int, world: int):
         """Later render / build_batch calls see only rank's glyphs (world <= 1: off)."""
-        _L().vg_manager_set_glyph_shard(self._h, rank, world)
+        if _L().vg_manager_set_glyph_shard(self._h, rank, world) != 0:
+            raise RuntimeError(_err())
+
+    def reduced_counters(self):
+        """(blocks, glyphs, pixels) of the last render with a multi-device renderer, as reduced over its lanes"""
+        out = (C.c_uint64 * 3)()
+        _L().vg_manager_reduced_counters(self._h, out)
+        return tuple(int(v) for v in out)
 
     def block_counts(self, font_id: str) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint32)
