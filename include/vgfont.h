@@ -76,6 +76,10 @@ void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per
 /* 1: flatten / close / scale / bbox on the GPU (device front-end of vgsdf.h; HIP renderer
  * only), 0: on host threads.  Same bytes either way. */
 void vg_manager_set_device_front_end(vg_manager *m, int on);
+/* 1 (default): blocks are assembled IN PLACE — the raster stores every bitmap where its block's finished PBF has it, the
+ * host writes the ~20 bytes around it (src/protobuf/glyphs.rs:66-70 without a second copy of the bitmaps); 0: bitmaps
+ * packed back to back, blocks encoded afterwards.  Same bytes either way. */
+void vg_manager_set_in_place_pbf(vg_manager *m, int on);
 int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
 int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
 /* manager.rs:39-53: the file's name table decides the font id (family/width/weight/style ->

@@ -50,7 +50,10 @@ typedef struct vgsdf_dbatch vgsdf_dbatch;
  * [seg_off[g], seg_off[g+1]).  (x0,y0,w,h) is RenderResult{x0,y0,width,height}
  * (src/render/result.rs:7-29), i.e. including the 3 px buffer on every side.
  * Output bitmap of glyph g: out[out_off[g] + (h-1-y)*w + x], row-major, top row first —
- * exactly renderer_precise.rs:78; out_off[g+1]-out_off[g] == w[g]*h[g].
+ * exactly renderer_precise.rs:78.  out_off is ascending with out_off[g] + w[g]*h[g] <= out_off[g+1]: normally the prefix
+ * sums of w*h (bitmaps packed back to back); a caller that assembles its output in place (the host façade lays the
+ * bitmaps out where the finished PBF blocks have them) leaves gaps, whose bytes are not written.  out_off[n_glyphs] is
+ * the size of the output buffer.
  */
 typedef struct {
 	uint32_t n_glyphs;
@@ -63,7 +66,7 @@ typedef struct {
 	const int32_t *y0;
 	const uint32_t *w;
 	const uint32_t *h;
-	const uint64_t *out_off; /* [n_glyphs+1] prefix sums of w*h */
+	const uint64_t *out_off; /* [n_glyphs+1] ascending, see above */
 } vgsdf_batch;
 
 /* Per-launch statistics (filled by vgsdf_batch_stats). */
@@ -181,9 +184,27 @@ typedef struct {
 	const float *coords;     /* [dat_off[n_glyphs]] */
 	const double *scale;     /* [n_glyphs] */
 	const double *shift_x;   /* [n_glyphs] */
+	/* In-place PBF assembly (both NULL: the bitmaps are packed back to back).  The output buffer becomes an ARENA of
+	 * finished glyphs-PBF blocks (src/protobuf/glyphs.rs:66-70): the device lays the glyphs out as the `glyphs` entries
+	 * of their fontstack message —
+	 *   0x1A varint(len) | 0x08 varint(id) | [0x12 varint(w h) BITMAP] | 0x18 width 0x20 height 0x28 left 0x30 top 0x38 advance
+	 * (glyph.rs:10-41; width = w - 6, height = h - 6, left = x0 + 3, top = y0 + h - 27: result.rs:66-76 after
+	 * renderer.rs:146; a glyph without a raster is PbfGlyph::empty, glyph.rs:60-70) — one after the other, and the raster
+	 * stores every BITMAP where the finished file has it; all other bytes are left for the caller, who knows id, advance and
+	 * the block headers and gets w, h, x0, y0 back in the rects (the host façade writes them: csrc/host/pbf.hpp,
+	 * write_pbf_entry_headers).  Glyph g starts at the running sum of what the glyphs before it occupy plus pbf_pre[g]:
+	 *   pbf_pre[g]  bytes reserved in front of glyph g's entry (the file + fontstack header of the block it opens, else 0)
+	 *   pbf_fix[g]  (1 + varint_len(id)) | (1 + varint_len(advance)) << 4
+	 * *out_bytes of vgsdf_outlines_wait is the size of the arena.  In the single-copy block of vgsdf_host_alloc() the two
+	 * arrays follow `kinds`: ... | kinds | (pad to a multiple of 4 bytes) | pbf_pre | pbf_fix. */
+	const uint32_t *pbf_pre; /* [n_glyphs] or NULL */
+	const uint8_t *pbf_fix;  /* [n_glyphs] or NULL */
 } vgsdf_outlines_packed;
 int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in, uint8_t *out_bitmaps, size_t out_capacity);
 int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
+/* after vgsdf_outlines_wait on a batch submitted with pbf_pre / pbf_fix: bitmap_at[g] = where in the arena the device placed
+ * glyph g's bitmap (for a glyph without a raster: the byte behind its id field, where the `width` tag goes) */
+int vgsdf_outlines_pbf_positions(vgsdf_ctx *ctx, uint64_t *bitmap_at);
 /* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */
 int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, double *sy, double *ex, double *ey);
 

@@ -349,3 +349,83 @@ def test_point_count_overflow_is_an_error_not_a_fault(vg, ctx):
     cmds["x1"], cmds["y1"] = 5.0, 5.0
     rects, _, n_segs = ctx.outlines_prepare(cmd_off, cmds, scale, shift)
     assert len(rects) == 1 and n_segs >= 0
+
+
+def _varint_len(v):
+    n = 1
+    while v >= 0x80:
+        v >>= 7
+        n += 1
+    return n
+
+
+def test_in_place_pbf_layout_at_the_c_abi(vg, fira_oracle):
+    """vgsdf_outlines_packed::pbf_pre / pbf_fix: the device lays the glyphs out as the `glyphs` entries of a fontstack
+    message (glyph.rs:10-41, fontstack.rs:9-25) and the raster stores every bitmap where the finished file has it.  Checked
+    against a Python restatement of the wire format: positions, arena size, and the bitmap bytes against the packed form."""
+    ref, c = vg.SdfContext(0), vg.SdfContext(0)
+    cps = list(range(0x20, 0x180))
+    cmd_off, cmds, scale, shift, _ = record(vg, fira_oracle, cps)
+    n = len(scale)
+    dat_off, kinds, coords = vg.SdfContext.pack_outlines(cmd_off, cmds)
+    ref.outlines_submit_packed(cmd_off, dat_off, kinds, coords, scale, shift, 1 << 20)
+    rects, packed, ob, ns = ref.outlines_wait()
+    ids = np.array(cps[:n], dtype=np.uint32) * 37 + 5        # any ids / advances: only their varint lengths matter here
+    adv = (np.arange(n, dtype=np.uint32) * 11) % 300
+    fix = np.array([(1 + _varint_len(int(i))) | ((1 + _varint_len(int(a))) << 4) for i, a in zip(ids, adv)], dtype=np.uint8)
+    pre = np.zeros(n, dtype=np.uint32)
+    pre[0], pre[100], pre[101] = 6 + 30, 6 + 31, 77          # "block" starts
+    for cap in (1 << 20, 64):                                # the second: the arena does not fit -> second launches
+        c.outlines_submit_packed(cmd_off, dat_off, kinds, coords, scale, shift, cap, pbf_pre=pre, pbf_fix=fix)
+        r2, arena, ob2, ns2 = c.outlines_wait()
+        assert r2.tobytes() == rects.tobytes() and ns2 == ns
+        if arena is None:
+            arena = c.outlines_render()
+        at = c.outlines_pbf_positions()
+        pos, poff = 0, 0
+        for g in range(n):
+            r = rects[g]
+            has = bool(r["has_raster"])
+            px = int(r["w"]) * int(r["h"]) if has else 0
+            idlen, advlen = int(fix[g]) & 15, int(fix[g]) >> 4
+            msg = idlen + advlen
+            if has:
+                left, top = int(r["x0"]) + 3, int(r["y0"]) + int(r["h"]) - 27
+                zz = lambda v: (v << 1) ^ (v >> 31)  # noqa: E731
+                msg += 1 + _varint_len(px) + px + 4 + _varint_len(int(r["w"]) - 6) + _varint_len(int(r["h"]) - 6) + \
+                    _varint_len(zz(left) & 0xFFFFFFFF) + _varint_len(zz(top) & 0xFFFFFFFF)
+            else:
+                msg += 8
+            want_at = pos + int(pre[g]) + 1 + _varint_len(msg) + idlen + ((1 + _varint_len(px)) if has else 0)
+            assert int(at[g]) == want_at, g
+            if has:
+                assert arena[want_at:want_at + px].tobytes() == packed[poff:poff + px].tobytes(), g
+                poff += px
+            pos += int(pre[g]) + 1 + _varint_len(msg) + msg
+        assert ob2 == pos and poff == ob
+    with pytest.raises(vg.VgsdfError, match="pbf_pre"):
+        c.outlines_submit_packed(cmd_off, dat_off, kinds, coords, scale, shift, 1 << 20, pbf_pre=pre)
+    ref.close()
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["fira", "noto_all"])
+def test_in_place_assembly_equals_encoding_afterwards(vg, name):
+    """FontManager with blocks assembled in place (default) and encoded after the render give the same files, through both
+    dispatchers; all of them carry the golden SHA-256s (test_pbf_sha_with_device_front_end covers the default)."""
+    disp, paths = set_paths(name)
+    m = vg.FontManager(True)
+    fid = m.add_font_with_name(disp, paths)
+    r = vg.Renderer.new_precise(0)
+    got = {}
+    for fe in (True, False):
+        for in_place in (True, False):
+            m.set_device_front_end(fe)
+            m.set_in_place_pbf(in_place)
+            w = vg.DummyWriter()
+            m.render_glyphs(w, r)
+            got[(fe, in_place)] = w.files
+    first = got[(True, True)]
+    assert all(v == first for v in got.values())
+    want = json.loads((GOLDEN / "pbf_sha256.json").read_text())[name]
+    assert all(hashlib.sha256(first[f"{fid}/{s}-{int(s) + 255}.pbf"]).hexdigest() == sha for s, sha in want.items())

@@ -150,3 +150,21 @@ def test_worker_pool_survives_many_short_forks(vg):
         assert {k: len(v) for k, v in w.files.items()} == want
         if i % 10 == 0:
             time.sleep(0.002)   # let the workers fall asleep on the condition variable
+
+
+def test_in_place_assembly_equals_encoding_afterwards_on_the_cpu(vg):
+    """host tessellation + dummy raster: blocks assembled in place in the output arena (bitmaps where the finished PBF has
+    them, headers written around them) equal blocks encoded from packed bitmaps"""
+    from conftest import NOTO
+    m = vg.FontManager(True)
+    m.add_font_with_name("Fira Sans Regular", [FIRA])
+    m.add_font_with_name("Noto Sans Regular", [NOTO])
+    r = vg.Renderer.new_dummy()
+    files = []
+    for in_place in (True, False):
+        m.set_in_place_pbf(in_place)
+        w = vg.DummyWriter()
+        m.render_glyphs(w, r)
+        files.append(w.files)
+    assert files[0] == files[1] and len(files[0]) == 512
+    assert len(files[0]["fira_sans_regular/0-255.pbf"]) == 80022  # recurse.rs:344

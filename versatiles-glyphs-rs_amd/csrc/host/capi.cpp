@@ -48,9 +48,10 @@ struct CallbackWriter final : vg::Writer {
 		if (cb && cb(user, p.c_str(), nullptr, 0, 1) != 0)
 			throw std::runtime_error("writer callback failed for " + p);
 	}
-	void write_file(const std::string &p, const std::vector<uint8_t> &d) override
+	void write_file(const std::string &p, const std::vector<uint8_t> &d) override { write_bytes(p, d.data(), d.size()); }
+	void write_bytes(const std::string &p, const uint8_t *d, size_t n) override
 	{
-		if (cb && cb(user, p.c_str(), d.data(), d.size(), 0) != 0)
+		if (cb && cb(user, p.c_str(), d, n, 0) != 0)
 			throw std::runtime_error("writer callback failed for " + p);
 	}
 };
@@ -106,6 +107,7 @@ void vg_manager_reduced_counters(const vg_manager *m, uint64_t counters[3]) { st
 vg_manager *vg_manager_new(int parallel) { return new vg_manager(parallel != 0); }
 void vg_manager_free(vg_manager *m) { delete m; }
 void vg_manager_set_device_front_end(vg_manager *m, int on) { m->m.set_device_front_end(on != 0); }
+void vg_manager_set_in_place_pbf(vg_manager *m, int on) { m->m.set_in_place_pbf(on != 0); }
 void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch)
 {
 	m->m.set_threads(threads);

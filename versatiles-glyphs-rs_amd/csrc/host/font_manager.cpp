@@ -290,19 +290,39 @@ void FontManager::write_families_json(Writer &writer) const
 	writer.write_file("font_families.json", build_font_families_json(*this));
 }
 
+// CPUs this process may actually run on at once: the cgroup's CPU quota when there is one (containers: cpu.max =
+// "quota period"), else the scheduler affinity / hardware_concurrency.
+static unsigned cpu_budget()
+{
+	unsigned n = std::thread::hardware_concurrency();
+	if (std::FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[32] = {0};
+		long long period = 0;
+		if (std::fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+			const long long quota = std::atoll(q);
+			if (quota > 0)
+				n = (unsigned)std::min<long long>(n ? n : 1u << 20, (quota + period - 1) / period);
+		}
+		std::fclose(f);
+	}
+	return n ? n : 1;
+}
+
 unsigned FontManager::worker_count() const
 {
 	if (!parallel_)
 		return 1;
 	if (threads_)
 		return threads_;
-	// default: the machine's threads, capped at one GPU's CPU share of an 8-GPU node (16);
-	// VG_THREADS or set_threads() override
+	// VG_THREADS or set_threads() override.  Default: twice the CPUs the process may use (measured on a 16-CPU quota:
+	// 8 / 16 / 24 / 32 / 48 / 64 threads give 4.3 / 5.4 / 5.7 / 5.9 / 5.3 / 4.9 M glyphs/s end to end on Noto Sans — the
+	// phases are a few hundred microseconds long and a second thread per CPU hides the wake-up of the first), at most 64:
+	// beyond that the fork / join of a phase costs more than the phase.  (Rounds 1-2 capped the pool at 16.)
 	if (const char *e = std::getenv("VG_THREADS"))
 		if (int v = std::atoi(e); v > 0)
 			return (unsigned)v;
-	const unsigned hc = std::thread::hardware_concurrency();
-	return hc ? std::min(hc, 16u) : 1;
+	static const unsigned budget = cpu_budget();
+	return std::max(1u, std::min(2 * budget, 64u));
 }
 
 ThreadPool &FontManager::pool()
@@ -716,6 +736,7 @@ struct CaptureWriter final : Writer {
 	std::vector<std::vector<uint8_t>> files;
 	void write_directory(const std::string &) override {}
 	void write_file(const std::string &, const std::vector<uint8_t> &data) override { files.push_back(data); }
+	void write_bytes(const std::string &, const uint8_t *data, size_t len) override { files.emplace_back(data, data + len); }
 };
 } // namespace
 
@@ -733,6 +754,7 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 	const unsigned per_lane = std::max(1u, worker_count() / world);
 	for (auto &c : children_) {
 		c->device_front_end_ = device_front_end_;
+		c->in_place_pbf_ = in_place_pbf_;
 		c->batch_blocks_ = batch_blocks_;
 		c->batch_blocks_set_ = batch_blocks_set_;
 		c->set_threads(per_lane);
@@ -888,7 +910,16 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 	G.n_jobs = n_jobs;
 	MergedOutlines &m = G.m;
 	m.jobs.resize(n_jobs);
-	m.layout(n_jobs, n_cmds, n_floats);
+	G.in_place = in_place_pbf_;
+	m.layout(n_jobs, n_cmds, n_floats, G.in_place);
+	// jobs of a task are contiguous in the merged batch: [task_g0[t], task_g0[t + 1])
+	G.task_g0.assign(G.g1 - G.g0 + 1, n_jobs);
+	{
+		size_t t_next = 0;
+		for (size_t i = 0; i < slices.size(); i++)
+			for (; t_next <= slices[i].task - G.g0; t_next++)
+				G.task_g0[t_next] = slices[i].g_job;
+	}
 	m.cmd_off[0] = 0;
 	m.dat_off[0] = 0;
 	tp.run(slices.size(), [&](size_t i, unsigned) {
@@ -923,11 +954,105 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 			m.jobs[g] = l.jobs[j];
 			m.scale[g] = l.scale[j];
 			m.shift_x[g] = l.shift_x[j];
+			if (m.pbf_fix) {
+				m.pbf_pre[g] = 0;
+				m.pbf_fix[g] = pbf_fix_of(l.jobs[j].id, l.jobs[j].advance);
+			}
 			m.cmd_off[g + 1] = G.slice_cmd[i] + (l.cmd_off[j + 1] - lc0);
 			m.dat_off[g + 1] = G.slice_dat[i] + (l.dat_off[j + 1] - ld0);
 		}
 	});
+	if (m.pbf_pre) // the first glyph of a block leaves room for the block's file + fontstack header in front of its entry
+		for (size_t t = G.g0; t < G.g1; t++) {
+			const uint32_t a = G.task_g0[t - G.g0], b = G.task_g0[t - G.g0 + 1];
+			if (a < b)
+				m.pbf_pre[a] = kPbfHeadRoom + pbf_block_fields(tasks[t].name->size(), tasks[t].block.range().size());
+		}
 	timings_.pack_s += now_s() - t1;
+}
+
+// In-place assembly: the raster has stored every bitmap of the group where its block's finished PBF has it (the arena
+// G.out, laid out by outline_plan from pbf_pre / pbf_fix); what is left is the ~20 bytes around each bitmap and the
+// block headers, written here on the pool.  A block without a glyph of this group is encoded on its own (32 bytes).
+// Every position the device reports is checked against this side's own arithmetic.
+void FontManager::fe_assemble_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer)
+{
+	ThreadPool &tp = pool();
+	const double t3 = now_s();
+	const size_t nb = G.g1 - G.g0;
+	MergedOutlines &m = G.m;
+	struct Piece {
+		const uint8_t *p = nullptr;
+		size_t n = 0;
+	};
+	std::vector<Piece> piece(nb);
+	// blocks without a glyph of this group (211 of a font's 256, typically): name + range only, ~35 bytes each, written
+	// into one store — a vector per file cost more than all the header bytes of the font together
+	size_t small_stride = 0;
+	for (size_t i = 0; i < nb; i++)
+		small_stride = std::max(small_stride, tasks[G.g0 + i].name->size() + 48);
+	std::vector<uint8_t> small(nb * small_stride);
+	std::atomic<uint64_t> n_raster{0}, n_pixels{0};
+	std::atomic<bool> mismatch{false};
+	uint8_t *arena = G.out.data();
+	tp.run(nb, [&](size_t i, unsigned) {
+		const Todo &td = tasks[G.g0 + i];
+		const uint32_t a = G.task_g0[i], b = G.task_g0[i + 1];
+		if (a == b) {
+			const std::string range = td.block.range();
+			uint8_t *entries = small.data() + i * small_stride + kPbfHeadRoom + pbf_block_fields(td.name->size(), range.size());
+			uint8_t *file = write_pbf_block_header(entries, *td.name, range, 0);
+			piece[i] = Piece{file, (size_t)(entries - file)};
+			return;
+		}
+		uint64_t rasters = 0, pixels = 0;
+		uint8_t *first = nullptr, *end = nullptr;
+		for (uint32_t g = a; g < b; g++) {
+			const vgsdf_rect &r = G.rects[g];
+			const GlyphJob &job = m.jobs[g];
+			const bool has = r.has_raster != 0;
+			// start of the entry from the bitmap's position: 0x1A varint(msg) 0x08 varint(id) [0x12 varint(w h)] come before it
+			const uint64_t px = has ? (uint64_t)r.w * r.h : 0;
+			const PbfEntrySize es = pbf_entry_size(job.id, job.advance, has, r.w, r.h, r.x0, r.y0);
+			const uint64_t before = es.bitmap_at;
+			if (G.pbf_at[g] < before || G.pbf_at[g] - before + es.total > G.out_bytes) {
+				mismatch = true; // the entry does not lie inside the arena
+				return;
+			}
+			uint8_t *entry = arena + (G.pbf_at[g] - before);
+			if (g == a) {
+				first = entry;
+			} else if (entry != end) {
+				mismatch = true; // the entries of a block follow each other without a gap
+				return;
+			}
+			end = entry + write_pbf_entry_headers(entry, job.id, job.advance, has, r.w, r.h, r.x0, r.y0);
+			rasters += has;
+			pixels += px;
+		}
+		if ((size_t)(first - arena) < m.pbf_pre[a]) {
+			mismatch = true;
+			return;
+		}
+		uint8_t *file = write_pbf_block_header(first, *td.name, td.block.range(), (size_t)(end - first));
+		piece[i] = Piece{file, (size_t)(end - file)};
+		n_raster += rasters;
+		n_pixels += pixels;
+	});
+	if (mismatch)
+		throw std::runtime_error("in-place PBF assembly: the device's layout of the arena differs from the host's");
+	const double t4 = now_s();
+	timings_.encode_s += t4 - t3;
+	for (size_t i = 0; i < nb; i++) {
+		writer.write_bytes(*tasks[G.g0 + i].name + "/" + tasks[G.g0 + i].block.filename(), piece[i].p, piece[i].n);
+		timings_.pbf_bytes += piece[i].n;
+	}
+	timings_.write_s += now_s() - t4;
+	timings_.blocks += nb;
+	timings_.glyphs += G.n_jobs;
+	timings_.rasters += n_raster;
+	timings_.pixels += n_pixels;
+	timings_.segments += G.n_segs;
 }
 
 // Rects + bitmaps of a rendered group -> PbfGlyphs per block (pool), written in task order.
@@ -1043,10 +1168,13 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		G.out_bytes = G.n_segs = 0;
 		if (in_flight[k & 1]) {
 			in_flight[k & 1] = false;
-			renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs);
+			renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs, G.in_place ? &G.pbf_at : nullptr);
 		}
 		timings_.device_s += now_s() - t;
-		fe_encode_write(tasks, G, writer);
+		if (G.in_place && G.n_jobs)
+			fe_assemble_write(tasks, G, writer);
+		else
+			fe_encode_write(tasks, G, writer);
 	};
 	try {
 		for (size_t k = 0; k < groups.size(); k++) {
@@ -1091,12 +1219,6 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 		const size_t nb = g1 - g0;
 
 		tessellate_and_pack(tasks, g0, g1, slices, packed_);
-		const double t1 = now_s();
-
-		renderer.render_packed(packed_);
-		const double t2 = now_s();
-		timings_.device_s += t2 - t1;
-
 		// slices of a task are contiguous and in code point order
 		std::vector<std::pair<size_t, size_t>> span(nb, {0, 0});
 		for (size_t i = 0; i < slices.size(); i++) {
@@ -1105,8 +1227,69 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 				sp.first = i;
 			sp.second = i + 1;
 		}
+		// In-place assembly (as the device front-end's, fe_assemble_write): the bitmaps are rendered where the blocks'
+		// finished PBFs have them.  The host knows every rect here, so it lays the arena out itself: out_off[g] = position
+		// of bitmap g, out_off[n] = size of the arena (vgsdf.h allows gaps between the bitmaps).
+		std::vector<uint64_t> entry_at; // per slice: first entry; entries of a slice follow each other
+		if (in_place_pbf_) {
+			const double tl = now_s();
+			entry_at.assign(slices.size() + 1, 0);
+			uint64_t pos = 0;
+			for (size_t i = 0; i < nb; i++)
+				for (size_t k = span[i].first; k < span[i].second; k++) {
+					const Slice &s = slices[k];
+					const GlyphBatch &l = workers_[s.worker].local;
+					if (k == span[i].first)
+						pos += kPbfHeadRoom + pbf_block_fields(tasks[g0 + i].name->size(), tasks[g0 + i].block.range().size());
+					entry_at[k] = pos;
+					uint32_t r = s.g_raster;
+					for (uint32_t j = s.job0; j < s.job1; j++) {
+						const GlyphJob &job = l.jobs[j];
+						const PbfEntrySize es = pbf_entry_size(job.id, job.advance, job.has_raster, job.width, job.height, job.x0, job.y0);
+						if (job.has_raster)
+							packed_.out_off[r++] = pos + es.bitmap_at;
+						pos += es.total;
+					}
+				}
+			entry_at[slices.size()] = pos;
+			packed_.out_off[packed_.n_raster] = pos;
+			packed_.out_bytes = pos;
+			packed_.out.ensure((size_t)pos + 1);
+			timings_.pack_s += now_s() - tl;
+		}
+		const double t1 = now_s();
+
+		renderer.render_packed(packed_);
+		const double t2 = now_s();
+		timings_.device_s += t2 - t1;
+
 		std::vector<std::vector<uint8_t>> encoded(nb);
+		struct Piece {
+			const uint8_t *p = nullptr;
+			size_t n = 0;
+		};
+		std::vector<Piece> piece(nb);
+		uint64_t n_pixels = 0;
+		for (const Slice &s : slices) {
+			const GlyphBatch &l = workers_[s.worker].local;
+			n_pixels += l.out_off[s.raster1] - l.out_off[s.raster0];
+		}
 		tp.run(nb, [&](size_t i, unsigned) {
+			if (in_place_pbf_ && span[i].second > span[i].first) {
+				uint8_t *arena = packed_.out.data();
+				uint8_t *first = arena + entry_at[span[i].first], *p = first;
+				for (size_t k = span[i].first; k < span[i].second; k++) {
+					const Slice &s = slices[k];
+					const GlyphBatch &l = workers_[s.worker].local;
+					for (uint32_t j = s.job0; j < s.job1; j++) {
+						const GlyphJob &job = l.jobs[j];
+						p += write_pbf_entry_headers(p, job.id, job.advance, job.has_raster, job.width, job.height, job.x0, job.y0);
+					}
+				}
+				uint8_t *file = write_pbf_block_header(first, *tasks[g0 + i].name, tasks[g0 + i].block.range(), (size_t)(p - first));
+				piece[i] = Piece{file, (size_t)(p - file)};
+				return;
+			}
 			std::vector<PbfGlyphRef> refs;
 			for (size_t k = span[i].first; k < span[i].second; k++) {
 				const Slice &s = slices[k];
@@ -1123,13 +1306,14 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 				}
 			}
 			encoded[i] = PbfGlyphs::encode(*tasks[g0 + i].name, tasks[g0 + i].block.range(), std::move(refs));
+			piece[i] = Piece{encoded[i].data(), encoded[i].size()};
 		});
 		const double t3 = now_s();
 		timings_.encode_s += t3 - t2;
 
 		for (size_t i = 0; i < nb; i++) {
-			writer.write_file(*tasks[g0 + i].name + "/" + tasks[g0 + i].block.filename(), encoded[i]);
-			timings_.pbf_bytes += encoded[i].size();
+			writer.write_bytes(*tasks[g0 + i].name + "/" + tasks[g0 + i].block.filename(), piece[i].p, piece[i].n);
+			timings_.pbf_bytes += piece[i].n;
 		}
 		timings_.write_s += now_s() - t3;
 
@@ -1137,7 +1321,7 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 		for (const Slice &s : slices)
 			timings_.glyphs += s.job1 - s.job0;
 		timings_.rasters += packed_.n_raster;
-		timings_.pixels += packed_.out_bytes;
+		timings_.pixels += n_pixels;
 		timings_.segments += packed_.n_seg;
 	}
 	timings_.total_s = now_s() - t_start;

@@ -34,6 +34,9 @@ struct Writer {
 	virtual ~Writer() = default;
 	virtual void write_directory(const std::string &path) = 0;
 	virtual void write_file(const std::string &path, const std::vector<uint8_t> &data) = 0;
+	// the same for bytes that live in someone else's buffer (a block assembled in place in the device's output arena):
+	// sinks that can take a pointer override it and save the copy
+	virtual void write_bytes(const std::string &path, const uint8_t *data, size_t len) { write_file(path, std::vector<uint8_t>(data, data + len)); }
 	virtual void finish() {} // writer/mod.rs:71-77
 };
 
@@ -185,6 +188,10 @@ public:
 	// false: host tessellation.  Both produce identical bytes.
 	void set_device_front_end(bool on) { device_front_end_ = on; }
 	bool device_front_end() const { return device_front_end_; }
+	// true (default): with the device front-end the blocks are assembled IN PLACE — the raster stores every bitmap where
+	// the finished PBF has it and the host writes the ~20 bytes around it; false: bitmaps packed back to back, blocks
+	// encoded afterwards (one more copy of every bitmap).  Same bytes either way.
+	void set_in_place_pbf(bool on) { in_place_pbf_ = on; }
 
 private:
 	struct Todo {
@@ -254,6 +261,9 @@ private:
 		std::vector<uint32_t> slice_ci, slice_cmd, slice_dat;
 		MergedOutlines m;
 		std::vector<vgsdf_rect> rects;
+		std::vector<uint64_t> pbf_at;       // in-place assembly: position of every job's bitmap in `out`
+		std::vector<uint32_t> task_g0;      // first job of every task of the group (+ one past the last)
+		bool in_place = false;
 		HostBuffer<uint8_t> out{true};
 		uint64_t out_bytes = 0, n_segs = 0;
 		uint32_t n_jobs = 0;
@@ -261,6 +271,8 @@ private:
 	FeGroup fe_group_[2]; // two groups in flight: one on the GPU, one being recorded / encoded
 	void fe_record(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
+	void fe_assemble_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
+	bool in_place_pbf_ = true;
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
 	bool parallel_;

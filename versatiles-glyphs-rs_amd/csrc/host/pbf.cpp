@@ -85,6 +85,74 @@ std::vector<uint8_t> PbfGlyphs::encode(const std::string &name, const std::strin
 	return out;
 }
 
+PbfEntrySize pbf_entry_size(uint32_t id, uint32_t advance, bool has_raster, uint32_t w, uint32_t h, int32_t x0, int32_t y0)
+{
+	const uint32_t width = has_raster ? w - 6u : 0u, height = has_raster ? h - 6u : 0u;
+	const int32_t left = has_raster ? (int32_t)((uint32_t)x0 + 3u) : 0, top = has_raster ? (int32_t)((uint32_t)y0 + h - 27u) : 0;
+	const uint64_t px = has_raster ? (uint64_t)w * h : 0;
+	uint64_t msg = 1 + varint_size(id) + 1 + varint_size(advance) + 1 + varint_size(width) + 1 + varint_size(height) + 1 +
+	               varint_size(zigzag(left)) + 1 + varint_size(zigzag(top));
+	if (has_raster)
+		msg += 1 + varint_size(px) + px;
+	PbfEntrySize e;
+	e.bitmap_at = 1 + varint_size(msg) + 1 + varint_size(id) + (has_raster ? 1 + varint_size(px) : 0);
+	e.total = 1 + varint_size(msg) + msg;
+	return e;
+}
+
+size_t write_pbf_entry_headers(uint8_t *at, uint32_t id, uint32_t advance, bool has_raster, uint32_t w, uint32_t h, int32_t x0,
+                               int32_t y0)
+{
+	// result.rs:66-76 after renderer.rs:146 (i32 arithmetic, two's complement); PbfGlyph::empty otherwise (glyph.rs:60-70)
+	const uint32_t width = has_raster ? w - 6u : 0u, height = has_raster ? h - 6u : 0u;
+	const int32_t left = has_raster ? (int32_t)((uint32_t)x0 + 3u) : 0, top = has_raster ? (int32_t)((uint32_t)y0 + h - 27u) : 0;
+	const uint64_t px = has_raster ? (uint64_t)w * h : 0;
+	uint64_t msg = 1 + varint_size(id) + 1 + varint_size(advance) + 1 + varint_size(width) + 1 + varint_size(height) + 1 +
+	               varint_size(zigzag(left)) + 1 + varint_size(zigzag(top));
+	if (has_raster)
+		msg += 1 + varint_size(px) + px;
+	uint8_t *p = at;
+	*p++ = 0x1A;
+	p = write_varint(p, msg);
+	*p++ = 0x08;
+	p = write_varint(p, id);
+	if (has_raster) {
+		*p++ = 0x12;
+		p = write_varint(p, px);
+		p += px; // the bitmap: stored by the raster
+	}
+	*p++ = 0x18;
+	p = write_varint(p, width);
+	*p++ = 0x20;
+	p = write_varint(p, height);
+	*p++ = 0x28;
+	p = write_varint(p, zigzag(left));
+	*p++ = 0x30;
+	p = write_varint(p, zigzag(top));
+	*p++ = 0x38;
+	p = write_varint(p, advance);
+	return (size_t)(p - at);
+}
+
+uint8_t *write_pbf_block_header(uint8_t *entries, const std::string &name, const std::string &range, size_t entries_bytes)
+{
+	const size_t fields = pbf_block_fields(name.size(), range.size());
+	const size_t stack = fields + entries_bytes;
+	uint8_t *p = entries - fields;
+	uint8_t *file = p - 1 - varint_size(stack); // right-aligned in the kPbfHeadRoom bytes in front of the fields
+	uint8_t *q = file;
+	*q++ = 0x0A; // glyphs.stacks
+	q = write_varint(q, stack);
+	*q++ = 0x0A; // fontstack.name
+	q = write_varint(q, name.size());
+	std::memcpy(q, name.data(), name.size());
+	q += name.size();
+	*q++ = 0x12; // fontstack.range
+	q = write_varint(q, range.size());
+	std::memcpy(q, range.data(), range.size());
+	return file;
+}
+
 std::vector<uint8_t> PbfGlyphs::into_vec() const
 {
 	std::vector<PbfGlyphRef> refs;

@@ -40,6 +40,42 @@ struct PbfGlyphRef {
 	uint32_t advance = 0;
 };
 
+// ---- in-place assembly (include/vgsdf.h, vgsdf_outlines_packed::pbf_pre / pbf_fix) ------------------------------
+// The raster stores every bitmap where the finished block file has it, inside an arena that holds the blocks of a
+// submission one after the other; the ~20 bytes around each bitmap and the block headers are written here once the
+// glyphs' rects are known.  The arithmetic below is the device's (csrc/outline_kernels.hip, pbf_place), which has
+// already placed the bitmaps.
+inline uint32_t pbf_varint_len(uint64_t v)
+{
+	uint32_t n = 1;
+	for (; v >= 0x80; v >>= 7)
+		n++;
+	return n;
+}
+// bytes reserved in front of a block's first entry: the file header 0x0A varint(stack) right-aligned in
+// kPbfHeadRoom bytes (so that nothing behind it depends on the length of that varint), then the name and range fields
+constexpr uint32_t kPbfHeadRoom = 6;
+inline uint32_t pbf_block_fields(size_t name_len, size_t range_len)
+{
+	return (uint32_t)(1 + pbf_varint_len(name_len) + name_len + 1 + pbf_varint_len(range_len) + range_len);
+}
+inline uint8_t pbf_fix_of(uint32_t id, uint32_t advance)
+{
+	return (uint8_t)((1 + pbf_varint_len(id)) | ((1 + pbf_varint_len(advance)) << 4));
+}
+// size of a glyph's entry and the offset of its bitmap in it (for a glyph without a raster: of the `width` tag)
+struct PbfEntrySize {
+	uint64_t total = 0, bitmap_at = 0;
+};
+PbfEntrySize pbf_entry_size(uint32_t id, uint32_t advance, bool has_raster, uint32_t w, uint32_t h, int32_t x0, int32_t y0);
+// One glyph of the arena: writes the entry's header bytes around the bitmap at `at` (= start of the entry) and returns
+// the entry's size.  has_raster, w, h, x0, y0: the glyph's rect (RenderResult incl. the 3 px buffer).
+size_t write_pbf_entry_headers(uint8_t *at, uint32_t id, uint32_t advance, bool has_raster, uint32_t w, uint32_t h, int32_t x0,
+                               int32_t y0);
+// The block's file header + name + range in front of its first entry (`entries` = start of the first entry, `stack` =
+// bytes of all its entries): returns the first byte of the file.
+uint8_t *write_pbf_block_header(uint8_t *entries, const std::string &name, const std::string &range, size_t entries_bytes);
+
 class PbfGlyphs {
 public:
 	// glyphs.rs:28-32

@@ -316,7 +316,7 @@ void Renderer::submit_outlines(int lane, const vgsdf_outlines_packed &v, HostBuf
 	// 448 bytes per glyph, the average of the fixture fonts) — a second step in wait only when that was too small
 	try {
 		if (out.capacity() == 0)
-			out.ensure((size_t)v.n_glyphs * 448 + 4096);
+			out.ensure((size_t)v.n_glyphs * 480 + 16384);
 		std::lock_guard<std::mutex> lock(mu_);
 		if (vgsdf_outlines_submit_packed(c, &v, out.data(), out.capacity()) != VGSDF_OK)
 			throw std::runtime_error(std::string("vgsdf_outlines_submit_packed: ") + vgsdf_last_error(c));
@@ -327,7 +327,7 @@ void Renderer::submit_outlines(int lane, const vgsdf_outlines_packed &v, HostBuf
 }
 
 void Renderer::wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
-                             uint64_t &n_segments, uint32_t n_glyphs) const
+                             uint64_t &n_segments, uint32_t n_glyphs, std::vector<uint64_t> *pbf_at) const
 {
 	lane &= 1;
 	vgsdf_ctx *c = lane == 0 ? ctx_ : ctx2_;
@@ -348,6 +348,11 @@ void Renderer::wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffe
 		out.ensure((size_t)out_bytes + 1);
 		if (vgsdf_outlines_render(c, out.data()) != VGSDF_OK)
 			throw std::runtime_error(std::string("vgsdf_outlines_render: ") + vgsdf_last_error(c));
+	}
+	if (pbf_at) { // in-place PBF assembly: where the device placed the bitmaps in the arena `out`
+		pbf_at->assign(n_glyphs, 0);
+		if (n_glyphs && vgsdf_outlines_pbf_positions(c, pbf_at->data()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_pbf_positions: ") + vgsdf_last_error(c));
 	}
 }
 

@@ -185,14 +185,19 @@ struct MergedOutlines {
 	uint32_t *cmd_off = nullptr, *dat_off = nullptr;
 	float *coords = nullptr;
 	uint8_t *kinds = nullptr;
-	void layout(uint32_t jobs_n, uint32_t n_cmds, uint32_t n_floats)
+	uint32_t *pbf_pre = nullptr; // in-place PBF assembly (vgsdf.h): bytes reserved in front of a glyph's entry
+	uint8_t *pbf_fix = nullptr;  // ... and the lengths of its id / advance fields; NULL when `with_pbf` was false
+	void layout(uint32_t jobs_n, uint32_t n_cmds, uint32_t n_floats, bool with_pbf = false)
 	{
 		n_jobs = jobs_n;
 		const size_t n = jobs_n;
 		const size_t o_shift = 8 * n, o_cmd = 16 * n, o_dat = o_cmd + 4 * (n + 1);
 		const size_t o_coords = (o_dat + 4 * (n + 1) + 7) & ~(size_t)7, o_kinds = o_coords + 4 * (size_t)n_floats;
-		blob.ensure(o_kinds + n_cmds + 16);
+		const size_t o_pre = (o_kinds + n_cmds + 3) & ~(size_t)3, o_fix = o_pre + 4 * n;
+		blob.ensure((with_pbf ? o_fix + n : o_kinds + n_cmds) + 16);
 		uint8_t *b = blob.data();
+		pbf_pre = with_pbf ? reinterpret_cast<uint32_t *>(b + o_pre) : nullptr;
+		pbf_fix = with_pbf ? b + o_fix : nullptr;
 		scale = reinterpret_cast<double *>(b);
 		shift_x = reinterpret_cast<double *>(b + o_shift);
 		cmd_off = reinterpret_cast<uint32_t *>(b + o_cmd);
@@ -210,6 +215,8 @@ struct MergedOutlines {
 		o.coords = coords;
 		o.scale = scale;
 		o.shift_x = shift_x;
+		o.pbf_pre = pbf_pre;
+		o.pbf_fix = pbf_fix;
 		return o;
 	}
 };
@@ -290,7 +297,7 @@ public:
 	// must stay untouched between the two calls; a lane is held from submit to wait.
 	void submit_outlines(int lane, const vgsdf_outlines_packed &batch, HostBuffer<uint8_t> &out) const;
 	void wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
-	                   uint64_t &n_segments, uint32_t n_glyphs) const;
+	                   uint64_t &n_segments, uint32_t n_glyphs, std::vector<uint64_t> *pbf_at = nullptr) const;
 
 	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one
 	// vgsdf_render_batch call; Dummy: zeros (renderer_dummy.rs).  Throws std::runtime_error.

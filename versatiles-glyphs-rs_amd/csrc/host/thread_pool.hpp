@@ -2,10 +2,16 @@
 // hands (font, block) tasks to rayon's global pool (src/font/manager.rs:117-121); here the
 // same tasks are tessellated / packed / encoded by these workers around one GPU submission.
 //
-// A font goes through three fork/joins (record, merge, encode) of ~0.1 ms each, so the hand-over matters as much
-// as the work: workers poll the generation counter for a short while after finishing (the next fork usually
-// follows within microseconds) before they sleep on the condition variable, and the caller polls the count of
-// busy workers before it sleeps (a futex wake-up of 15 sleeping threads costs 20-50 us per fork).
+// A font goes through three or four fork/joins (record, merge, assemble) of 50-150 us each, so the hand-over matters
+// as much as the work:
+//  * a fork is ONE store: generation, item count and next item live in one 64-bit word, workers claim items with a
+//    compare-exchange on it, so a worker that wakes up late — for a fork that is already over — can neither take an
+//    item that does not exist (the count it checks against is the word's own) nor delay anybody;
+//  * the join waits for the ITEMS, not for the workers: whoever is awake does the work, and the caller returns when
+//    the last item is done (rounds 1-2 waited until every worker had checked in, i.e. for the slowest of 15-31
+//    futex wake-ups, 50-90 us per fork when the workers had gone to sleep behind a device wait);
+//  * workers poll the word for ~100 us after a fork before they sleep on the condition variable (the next fork
+//    usually follows within microseconds), and the caller polls the count of finished items before it sleeps.
 #pragma once
 #include <atomic>
 #include <chrono>
@@ -13,6 +19,7 @@
 #include <exception>
 #include <functional>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,8 +37,8 @@ public:
 	{
 		{
 			std::lock_guard<std::mutex> l(mu_);
-			stop_ = true;
-			gen_.fetch_add(1, std::memory_order_release);
+			stop_.store(true, std::memory_order_release);
+			state_.store(word(gen_of(state_.load(std::memory_order_relaxed)) + 1, 0, 0), std::memory_order_seq_cst);
 		}
 		cv_.notify_all();
 		for (auto &th : threads_)
@@ -45,26 +52,33 @@ public:
 	{
 		if (n == 0)
 			return;
-		{
-			std::lock_guard<std::mutex> l(mu_);
-			fn_ = &fn;
-			total_ = n;
-			next_.store(0);
-			failed_.store(false);
-			error_.clear();
-			pending_.store(n_ - 1, std::memory_order_relaxed);
-			gen_.fetch_add(1, std::memory_order_release);
-		}
-		if (sleepers_.load(std::memory_order_acquire) != 0)
+		if (n > kMaxItems)
+			throw std::runtime_error("ThreadPool::run: more than 2^24 - 1 items");
+		// (no item of the previous fork is left: its word says next == count, nobody can claim anything until the store below)
+		fn_.store(&fn, std::memory_order_relaxed);
+		done_.store(0, std::memory_order_relaxed);
+		failed_.store(false, std::memory_order_relaxed);
+		const uint32_t gen = (gen_of(state_.load(std::memory_order_relaxed)) + 1) & 0xFFFFu;
+		// the fork: everything above is visible to whoever reads the word.  Sequentially consistent with the workers'
+		// count of sleepers (store here, load there and the other way round): a worker on its way to sleep either sees
+		// this fork or is seen here
+		state_.store(word(gen, (uint32_t)n, 0), std::memory_order_seq_cst);
+		if (sleepers_.load(std::memory_order_seq_cst) != 0) {
+			{
+				std::lock_guard<std::mutex> l(mu_); // (pairs with the sleepers' predicate check: no lost wake-up)
+			}
 			cv_.notify_all();
-		work(0);
-		if (!poll([this] { return pending_.load(std::memory_order_acquire) == 0; })) {
-			std::unique_lock<std::mutex> l(mu_);
-			done_cv_.wait(l, [this] { return pending_.load(std::memory_order_acquire) == 0; });
 		}
-		fn_ = nullptr;
-		if (failed_.load())
+		work(0, gen);
+		const uint32_t total = (uint32_t)n;
+		if (!poll([&] { return done_.load(std::memory_order_acquire) == total; })) {
+			std::unique_lock<std::mutex> l(done_mu_);
+			done_cv_.wait(l, [&] { return done_.load(std::memory_order_acquire) == total; });
+		}
+		if (failed_.load(std::memory_order_acquire)) {
+			std::lock_guard<std::mutex> l(err_mu_);
 			throw std::runtime_error(error_);
+		}
 	}
 
 private:
@@ -84,58 +98,66 @@ private:
 				return ready();
 		}
 	}
-	void work(unsigned id)
+	// items of fork `gen`, one compare-exchange each, until there is none left or the word has moved on
+	void work(unsigned id, uint32_t gen)
 	{
 		for (;;) {
-			const size_t i = next_.fetch_add(1);
-			if (i >= total_ || failed_.load())
+			uint64_t v = state_.load(std::memory_order_acquire);
+			if (gen_of(v) != gen)
 				return;
-			try {
-				(*fn_)(i, id);
-			} catch (const std::exception &e) {
-				std::lock_guard<std::mutex> l(err_mu_);
-				if (!failed_.exchange(true))
-					error_ = e.what();
+			const uint32_t i = (uint32_t)(v & kMaxItems), total = (uint32_t)((v >> 24) & kMaxItems);
+			if (i >= total)
+				return;
+			if (!state_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire))
+				continue;
+			if (!failed_.load(std::memory_order_relaxed)) {
+				try {
+					(*fn_.load(std::memory_order_relaxed))(i, id);
+				} catch (const std::exception &e) {
+					std::lock_guard<std::mutex> l(err_mu_);
+					if (!failed_.exchange(true))
+						error_ = e.what();
+				}
+			}
+			if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == total) { // the last item: the caller may be asleep
+				{
+					std::lock_guard<std::mutex> l(done_mu_); // (pairs with the caller's wait: no lost wake-up)
+				}
+				done_cv_.notify_one();
 			}
 		}
 	}
 	void loop(unsigned id)
 	{
-		uint64_t seen = 0;
+		uint32_t seen = 0;
 		for (;;) {
-			if (!poll([&] { return gen_.load(std::memory_order_acquire) != seen; })) {
+			auto moved = [&] { return gen_of(state_.load(std::memory_order_acquire)) != seen; };
+			if (!poll(moved)) {
 				std::unique_lock<std::mutex> l(mu_);
-				sleepers_.fetch_add(1, std::memory_order_release);
-				cv_.wait(l, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-				sleepers_.fetch_sub(1, std::memory_order_release);
+				sleepers_.fetch_add(1, std::memory_order_seq_cst);
+				cv_.wait(l, [&] { return gen_of(state_.load(std::memory_order_seq_cst)) != seen; });
+				sleepers_.fetch_sub(1, std::memory_order_seq_cst);
 			}
-			{
-				// (the fields of the fork are published under the mutex: take it once before reading them)
-				std::lock_guard<std::mutex> l(mu_);
-				seen = gen_.load(std::memory_order_acquire);
-				if (stop_)
-					return;
-			}
-			work(id);
-			if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-				std::lock_guard<std::mutex> l(mu_); // (pairs with the caller's wait: no lost wake-up)
-				done_cv_.notify_one();
-			}
+			if (stop_.load(std::memory_order_acquire))
+				return;
+			seen = gen_of(state_.load(std::memory_order_acquire));
+			work(id, seen);
 		}
 	}
 
 	unsigned n_;
 	std::vector<std::thread> threads_;
-	std::mutex mu_, err_mu_;
+	std::mutex mu_, done_mu_, err_mu_;
 	std::condition_variable cv_, done_cv_;
-	const std::function<void(size_t, unsigned)> *fn_ = nullptr;
-	size_t total_ = 0;
-	std::atomic<size_t> next_{0};
-	std::atomic<bool> failed_{false};
+	static constexpr uint64_t kMaxItems = 0xFFFFFFull;
+	static uint64_t word(uint32_t gen, uint32_t total, uint32_t next) { return ((uint64_t)gen << 48) | ((uint64_t)total << 24) | next; }
+	static uint32_t gen_of(uint64_t v) { return (uint32_t)(v >> 48); }
+	std::atomic<const std::function<void(size_t, unsigned)> *> fn_{nullptr}; // published by the store to state_
+	std::atomic<uint64_t> state_{0}; // generation (16 bits) | item count (24) | next item (24)
+	std::atomic<uint32_t> done_{0};
+	std::atomic<bool> failed_{false}, stop_{false};
 	std::string error_;
-	std::atomic<unsigned> pending_{0}, sleepers_{0};
-	std::atomic<uint64_t> gen_{0};
-	bool stop_ = false;
+	std::atomic<unsigned> sleepers_{0};
 };
 
 } // namespace vg

@@ -27,6 +27,7 @@ public:
 	void write_directory(const std::string &path) override;
 	void write_file(const std::string &path, const std::vector<uint8_t> &data) override;
 	void write_file(const std::string &path, const uint8_t *data, size_t len);
+	void write_bytes(const std::string &path, const uint8_t *data, size_t len) override { write_file(path, data, len); }
 	void finish() override;
 
 private:
@@ -47,6 +48,7 @@ public:
 	void write_directory(const std::string &path) override;
 	void write_file(const std::string &path, const std::vector<uint8_t> &data) override;
 	void write_file(const std::string &path, const uint8_t *data, size_t len);
+	void write_bytes(const std::string &path, const uint8_t *data, size_t len) override { write_file(path, data, len); }
 
 private:
 	std::string folder_;

@@ -78,7 +78,8 @@ int vgsdf_outline_rings(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, 
 int vgsdf_outline_plan(const vgsdf::OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
                        uint32_t span_budget, uint32_t tile_cap, vgsdf::GlyphDesc *descs, uint2 *tiles, vgsdf::PlanHeader *hdr,
                        const uint32_t *error_flag, unsigned long long seg_cap, unsigned long long out_cap, uint32_t launch_spans,
-                       hipStream_t stream);
+                       const uint32_t *pbf_pre /* NULL: bitmaps packed back to back */, const uint8_t *pbf_fix,
+                       unsigned long long *pbf_at /* [n_glyphs] positions of the bitmaps in the arena */, hipStream_t stream);
 int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const uint8_t *cmd_open, const double *scale,
                                 const double *shift_x,
                                 const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,

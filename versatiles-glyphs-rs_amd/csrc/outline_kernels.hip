@@ -920,12 +920,51 @@ __device__ __forceinline__ unsigned long long block_exclusive_sum(unsigned long 
 	return s_wave[wv] + incl - v;
 }
 
+// bytes of a protobuf varint
+__device__ __forceinline__ uint32_t varint_len(unsigned long long v)
+{
+	uint32_t n = 1;
+	for (; v >= 0x80; v >>= 7)
+		n++;
+	return n;
+}
+
+// In-place PBF assembly (vgsdf.h, vgsdf_outlines_packed::pbf_pre / pbf_fix): what glyph `r` occupies in the arena of
+// finished PBF blocks — `pre` reserved bytes in front of it (the block's file and fontstack header when it is the first
+// glyph of its block), then its `glyphs` entry of the fontstack message (src/protobuf/glyph.rs:10-41, fontstack.rs:9-25):
+//   0x1A varint(msg) | 0x08 varint(id) | [0x12 varint(w h) bitmap] | 0x18 width 0x20 height 0x28 left 0x30 top 0x38 advance
+// with width = w - 6, height = h - 6, left = x0 + 3, top = y0 + h - 27 (src/render/result.rs:66-76 after renderer.rs:146).
+// fix = (1 + varint_len(id)) | (1 + varint_len(advance)) << 4, from the host (it knows id and advance).
+// Returns the bytes taken, sets `bitmap_at` to the bitmap's offset in them.  The host writes the headers with the same
+// arithmetic (csrc/host/pbf.hpp, pbf_entry_layout) once the rects are back.
+__device__ __forceinline__ unsigned long long pbf_place(const OutlineRect &r, uint32_t pre, uint32_t fix, unsigned long long &bitmap_at)
+{
+	const uint32_t idlen = fix & 15u, advlen = fix >> 4;
+	unsigned long long msg = idlen + advlen;
+	const unsigned long long px = r.has_raster ? (unsigned long long)r.w * r.h : 0ull;
+	uint32_t bm_hdr = 0;
+	if (r.has_raster) {
+		bm_hdr = 1u + varint_len(px);
+		msg += bm_hdr + px;
+		const uint32_t left = (uint32_t)r.x0 + 3u, top = (uint32_t)r.y0 + r.h - 27u; // two's complement, as i32 arithmetic wraps
+		const uint32_t zl = (left << 1) ^ (uint32_t)((int32_t)left >> 31), zt = (top << 1) ^ (uint32_t)((int32_t)top >> 31);
+		msg += 4u + varint_len(r.w - 6u) + varint_len(r.h - 6u) + varint_len(zl) + varint_len(zt);
+	} else {
+		msg += 8u; // PbfGlyph::empty: width, height, left, top = 0 (glyph.rs:60-70), one byte each behind its tag
+	}
+	const uint32_t ent_hdr = 1u + varint_len(msg);
+	bitmap_at = (unsigned long long)pre + ent_hdr + idlen + bm_hdr;
+	return (unsigned long long)pre + ent_hdr + msg;
+}
+
 __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *__restrict__ rects, uint32_t n_glyphs, int span_list,
                                                              uint32_t delta_cap, uint32_t span_max, uint32_t span_budget,
                                                              uint32_t tile_cap, GlyphDesc *__restrict__ descs,
                                                              uint2 *__restrict__ tiles, PlanHeader *__restrict__ hdr,
                                                              const uint32_t *__restrict__ error_flag, unsigned long long seg_cap,
-                                                             unsigned long long out_cap, uint32_t launch_spans)
+                                                             unsigned long long out_cap, uint32_t launch_spans,
+                                                             const uint32_t *__restrict__ pbf_pre, const uint8_t *__restrict__ pbf_fix,
+                                                             unsigned long long *__restrict__ pbf_at)
 {
 	__shared__ unsigned long long s_wave[kPlanThreads / 64 + 1];
 	__shared__ uint32_t s_hist[2][kPlanBuckets]; // spans per (class, bucket); then the bucket's write cursor
@@ -982,20 +1021,27 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	}
 	{
 		unsigned long long my_s = 0, my_p = 0;
-		auto sum_one = [&](const OutlineRect &r) {
+		// output bytes of a glyph: its bitmap, or — in-place PBF assembly — everything it occupies in the arena
+		auto sum_one = [&](uint32_t g, const OutlineRect &r) {
 			if (r.has_raster) {
 				my_s += r.n_segments;
-				my_p += (unsigned long long)r.w * r.h;
 				bad |= (unsigned long long)r.w * r.h > 0xFFFFFFFFull - 256ull;
+			}
+			if (pbf_fix != nullptr) {
+				unsigned long long at;
+				my_p += pbf_place(r, pbf_pre[g], pbf_fix[g], at);
+			} else if (r.has_raster) {
+				my_p += (unsigned long long)r.w * r.h;
 			}
 		};
 		if (kept) {
 #pragma unroll
 			for (uint32_t j = 0; j < kKeep; j++)
-				sum_one(kr[j]);
+				if (g_lo + j < g_hi)
+					sum_one(g_lo + j, kr[j]);
 		} else {
 			for (uint32_t g = g_lo; g < g_hi; g++)
-				sum_one(rects[g]);
+				sum_one(g, rects[g]);
 		}
 		unsigned long long tot_s, tot_p;
 		unsigned long long so = block_exclusive_sum(my_s, s_wave, tot_s);
@@ -1014,10 +1060,18 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 			d.y0 = r.y0;
 			d.w = r.has_raster ? r.w : 0;
 			d.h = r.has_raster ? r.h : 0;
-			d.out_off = po;
+			if (pbf_fix != nullptr) {
+				unsigned long long at;
+				const unsigned long long took = pbf_place(r, pbf_pre[g], pbf_fix[g], at);
+				d.out_off = po + at; // the raster stores the bitmap where the finished file has it
+				pbf_at[g] = po + at; // (read back with the rects: the host writes the bytes around it)
+				po += took;
+			} else {
+				d.out_off = po;
+				po += px;
+			}
 			descs[g] = d;
 			so += segs;
-			po += px;
 			if (nspans)
 				atomicAdd(&s_hist[cls][plan_bucket(weight)], nspans);
 		};
@@ -1279,10 +1333,11 @@ extern "C" int vgsdf_outline_rings(const OutlineCmd *cmds, const uint32_t *cmd_o
 extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, int span_list, uint32_t delta_cap, uint32_t span_max,
                                   uint32_t span_budget, uint32_t tile_cap, GlyphDesc *descs, uint2 *tiles, PlanHeader *hdr,
                                   const uint32_t *error_flag, unsigned long long seg_cap, unsigned long long out_cap,
-                                  uint32_t launch_spans, hipStream_t stream)
+                                  uint32_t launch_spans, const uint32_t *pbf_pre, const uint8_t *pbf_fix,
+                                  unsigned long long *pbf_at, hipStream_t stream)
 {
 	hipLaunchKernelGGL(outline_plan, dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
-	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans);
+	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at);
 	return (int)hipGetLastError();
 }
 

@@ -129,9 +129,11 @@ struct DevBuf {
 struct FePending {
 	bool active = false;
 	uint32_t n = 0, n_cmds = 0;
-	size_t hdr_off = 0, rh_bytes = 0;
+	size_t hdr_off = 0, rh_bytes = 0, at_off = 0; // rects | PlanHeader | (in-place PBF assembly) bitmap positions u64[n]
 	bool span = false, spec = false;
 	bool spec_direct = false; // the raster stores through the device mapping of the caller's page-locked buffer
+	const uint32_t *d_pbf_pre = nullptr; // device copies of the in-place PBF inputs (NULL: bitmaps packed back to back)
+	const uint8_t *d_pbf_fix = nullptr;
 	uint8_t *spec_out = nullptr, *d_spec = nullptr; // destination of the raster enqueued behind the front-end
 	size_t spec_cap = 0;
 	uint32_t launch_spans = 0, span_max = 4, span_budget = 16;
@@ -141,7 +143,7 @@ struct FePending {
 struct FrontEnd {
 	// device: inputs, per-command / per-ring intermediates, results of measure + plan, the resident batch
 	DevBuf cmds, kinds, coords, meta, cmd_open, counts, pt_local, cmd_box, cmd_mask, rings, cmd_ring, rects_hdr, descs, tiles, flag;
-	DevBuf seg, out, boxes; // seg: records {sx, sy, ex, ey}
+	DevBuf seg, out, boxes, pbf_in; // seg: records {sx, sy, ex, ey}
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
 	uint32_t last_spans = 0;          // work-list length of the previous batch (grid guess of the one-submission form)
@@ -158,7 +160,7 @@ struct FrontEnd {
 	}
 	void release_all()
 	{
-		for (DevBuf *b : {&cmds, &kinds, &coords, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &cmd_mask, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes,
+		for (DevBuf *b : {&cmds, &kinds, &coords, &meta, &cmd_open, &counts, &pt_local, &cmd_box, &cmd_mask, &rings, &cmd_ring, &rects_hdr, &descs, &tiles, &flag, &seg, &out, &boxes, &pbf_in,
 		                  &h_rects, &h_stage})
 			b->release();
 	}
@@ -486,9 +488,9 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 		return VGSDF_E_ARG;
 	}
 	// validate shapes on the host BEFORE anything is launched: the kernel indexes with them
-	uint64_t n_tiles = 0, n_pairs = 0;
-	if (n && (in->seg_off[0] != 0 || in->out_off[0] != 0)) {
-		ctx->err = "vgsdf_batch_upload: seg_off[0] and out_off[0] must be 0";
+	uint64_t n_tiles = 0, n_pairs = 0, n_pixels = 0;
+	if (n && in->seg_off[0] != 0) {
+		ctx->err = "vgsdf_batch_upload: seg_off[0] must be 0";
 		return VGSDF_E_ARG;
 	}
 	for (uint32_t g = 0; g < n; g++) {
@@ -497,18 +499,19 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 			return VGSDF_E_ARG;
 		}
 		const uint64_t px = (uint64_t)in->w[g] * in->h[g];
-		if (px > 0xFFFFFFFFull - VGSDF_TILE_PIXELS || in->out_off[g + 1] - in->out_off[g] != px) {
-			ctx->err = "vgsdf_batch_upload: out_off inconsistent with w*h";
+		if (px > 0xFFFFFFFFull - VGSDF_TILE_PIXELS || in->out_off[g + 1] < in->out_off[g] || in->out_off[g + 1] - in->out_off[g] < px) {
+			ctx->err = "vgsdf_batch_upload: out_off inconsistent with w*h (bitmap g needs out_off[g] + w*h <= out_off[g+1])";
 			return VGSDF_E_ARG;
 		}
 		n_tiles += (px + VGSDF_TILE_PIXELS - 1) / VGSDF_TILE_PIXELS;
 		n_pairs += px * (in->seg_off[g + 1] - in->seg_off[g]);
+		n_pixels += px;
 	}
 	if (n_tiles > 0x7FFFFFFFull) {
 		ctx->err = "vgsdf_batch_upload: batch too large (tile count exceeds 2^31-1); split it";
 		return VGSDF_E_ARG;
 	}
-	const uint64_t n_pix = n ? in->out_off[n] : 0;
+	const uint64_t n_pix = n ? in->out_off[n] : 0; // size of the output buffer (>= the pixels: gaps are allowed)
 
 	vgsdf_dbatch *b = new (std::nothrow) vgsdf_dbatch();
 	if (!b) {
@@ -517,10 +520,10 @@ static int upload_impl(vgsdf_ctx *ctx, const vgsdf_batch *in, vgsdf_dbatch **out
 	}
 	b->stats.n_glyphs = n;
 	b->stats.n_segments = n_seg;
-	b->stats.n_pixels = n_pix;
+	b->stats.n_pixels = n_pixels;
 	b->stats.n_pairs = n_pairs;
 	b->stats.n_tiles = n_tiles;
-	b->stats.alg_bytes = 32 * n_seg + 32 * (uint64_t)n + n_pix;
+	b->stats.alg_bytes = 32 * n_seg + 32 * (uint64_t)n + n_pixels;
 	b->out_bytes = n_pix;
 
 	const size_t A = 256;
@@ -813,7 +816,8 @@ int fe_launch_plan(vgsdf_ctx *ctx, FrontEnd &fe, uint32_t spans_launched)
 	return vgsdf_outline_plan(d.rects, p.n, p.span ? 1 : 0, (uint32_t)vgsdf_filtered_delta_cap(), p.span_max, p.span_budget,
 	                          (uint32_t)std::min<size_t>(fe.tile_cap, 0x7FFFFFFFu), d.descs, (uint2 *)fe.tiles.p, d.hdr,
 	                          (const uint32_t *)fe.flag.p, (unsigned long long)fe.seg_cap, (unsigned long long)p.spec_cap,
-	                          spans_launched, ctx->stream);
+	                          spans_launched, p.d_pbf_pre, p.d_pbf_fix,
+	                          p.d_pbf_fix ? (unsigned long long *)((uint8_t *)fe.rects_hdr.p + p.at_off) : nullptr, ctx->stream);
 }
 int fe_launch_emit(vgsdf_ctx *ctx, FrontEnd &fe)
 {
@@ -856,6 +860,8 @@ struct FeInput {
 	const uint32_t *dat_off = nullptr;
 	const uint8_t *kinds = nullptr;
 	const float *coords = nullptr;
+	const uint32_t *pbf_pre = nullptr; // in-place PBF assembly (vgsdf_outlines_packed): both or neither
+	const uint8_t *pbf_fix = nullptr;
 	bool packed = false;
 };
 
@@ -866,6 +872,10 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		return VGSDF_E_ARG;
 	if (!in || (in->n_glyphs && (!in->cmd_off || !in->scale || !in->shift_x || (in->packed && !in->dat_off)))) {
 		ctx->err = "vgsdf_outlines: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	if ((in->pbf_pre == nullptr) != (in->pbf_fix == nullptr) || (in->pbf_fix && !in->packed)) {
+		ctx->err = "vgsdf_outlines: pbf_pre and pbf_fix come together (packed form only)";
 		return VGSDF_E_ARG;
 	}
 	static_assert(sizeof(vgsdf_outline_cmd) == sizeof(vgsdf::OutlineCmd), "ABI struct mirrors the kernel struct");
@@ -948,12 +958,16 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	const size_t meta_bytes = meta_dat + (in->packed ? 4 * (size_t)(n + 1) : 0);
 	// packed input whose arrays sit back to back in one page-locked block, in the order of the device's own layout
 	// (scale | shift_x | cmd_off | dat_off | pad to 8 | coords | kinds): ONE copy instead of three
+	// (with in-place PBF assembly: ... | kinds | pad to 4 | pbf_pre u32[n] | pbf_fix u8[n])
 	const size_t blob_coords = (meta_bytes + 7) & ~(size_t)7, blob_kinds = blob_coords + 4 * (size_t)n_floats;
-	const size_t blob_bytes = blob_kinds + n_cmds;
+	const bool pbf = in->pbf_fix != nullptr;
+	const size_t blob_pre = (blob_kinds + n_cmds + 3) & ~(size_t)3, blob_fix = blob_pre + 4 * (size_t)n;
+	const size_t blob_bytes = pbf ? blob_fix + n : blob_kinds + n_cmds;
 	const uint8_t *hb = (const uint8_t *)in->scale;
 	const bool blob = in->packed && (const uint8_t *)in->shift_x == hb + meta_shift && (const uint8_t *)in->cmd_off == hb + meta_off &&
 	                  (const uint8_t *)in->dat_off == hb + meta_dat && (const uint8_t *)in->coords == hb + blob_coords &&
-	                  in->kinds == hb + blob_kinds && is_pinned(hb, blob_bytes);
+	                  in->kinds == hb + blob_kinds &&
+	                  (!pbf || ((const uint8_t *)in->pbf_pre == hb + blob_pre && in->pbf_fix == hb + blob_fix)) && is_pinned(hb, blob_bytes);
 	FE_TRY(fe.meta.ensure((blob ? blob_bytes : meta_bytes) + 16));
 	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
@@ -964,7 +978,8 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	FE_TRY(fe.rings.ensure(sizeof(vgsdf::RingRec) * (size_t)(n_cmds + 1)));
 	FE_TRY(fe.cmd_ring.ensure(4 * (size_t)(n_cmds + 1)));
 	p.hdr_off = align_up(sizeof(vgsdf::OutlineRect) * (size_t)n, 16); // rects and totals: one block, one read-back
-	p.rh_bytes = p.hdr_off + sizeof(vgsdf::PlanHeader);
+	p.at_off = align_up(p.hdr_off + sizeof(vgsdf::PlanHeader), 16);
+	p.rh_bytes = pbf ? p.at_off + 8 * (size_t)n : p.hdr_off + sizeof(vgsdf::PlanHeader);
 	FE_TRY(fe.rects_hdr.ensure(p.rh_bytes));
 	FE_TRY(fe.h_rects.ensure(p.rh_bytes));
 	FE_TRY(fe.descs.ensure(sizeof(vgsdf::GlyphDesc) * (size_t)n + 16));
@@ -981,6 +996,10 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hb, blob_bytes, hipMemcpyHostToDevice, st));
 		d_coords = (const float *)((const uint8_t *)fe.meta.p + blob_coords);
 		d_kinds = (const uint8_t *)fe.meta.p + blob_kinds;
+		if (pbf) {
+			p.d_pbf_pre = (const uint32_t *)((const uint8_t *)fe.meta.p + blob_pre);
+			p.d_pbf_fix = (const uint8_t *)fe.meta.p + blob_fix;
+		}
 	} else if (in->packed) {
 		FE_TRY(fe.kinds.ensure((size_t)n_cmds + 16));
 		FE_TRY(fe.coords.ensure(4 * (size_t)n_floats + 16));
@@ -1001,6 +1020,13 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		if (in->packed)
 			std::memcpy(hm + meta_dat, in->dat_off, 4 * (size_t)(n + 1));
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
+	}
+	if (pbf && !blob) { // arrays that do not sit in the single-copy block: their own copies
+		FE_TRY(fe.pbf_in.ensure(5 * (size_t)n + 16));
+		FE_TRY(hipMemcpyAsync(fe.pbf_in.p, in->pbf_pre, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+		FE_TRY(hipMemcpyAsync((uint8_t *)fe.pbf_in.p + 4 * (size_t)n, in->pbf_fix, (size_t)n, hipMemcpyHostToDevice, st));
+		p.d_pbf_pre = (const uint32_t *)fe.pbf_in.p;
+		p.d_pbf_fix = (const uint8_t *)fe.pbf_in.p + 4 * (size_t)n;
 	}
 	FE_TRY(hipMemsetAsync(fe.flag.p, 0, 16, st));
 	const FeDev d = fe_dev(fe);
@@ -1111,11 +1137,13 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	}
 	const double tr3 = fe_now();
 
-	uint64_t n_pairs = 0;
+	uint64_t n_pairs = 0, n_pixels = 0;
 	for (uint32_t g = 0; g < n; g++) {
 		const vgsdf_rect &r = rects_out[g];
-		if (r.has_raster)
+		if (r.has_raster) {
 			n_pairs += (uint64_t)r.w * r.h * r.n_segments;
+			n_pixels += (uint64_t)r.w * r.h;
+		}
 	}
 	const FeDev d = fe_dev(fe);
 	fe.n_segs = (uint32_t)hdr.n_segments;
@@ -1123,10 +1151,10 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	vgsdf_dbatch &b = fe.batch;
 	b.stats.n_glyphs = n;
 	b.stats.n_segments = fe.n_segs;
-	b.stats.n_pixels = fe.out_bytes;
+	b.stats.n_pixels = n_pixels; // (out_bytes is larger with in-place PBF assembly: headers and gaps)
 	b.stats.n_pairs = n_pairs;
 	b.stats.n_tiles = hdr.n_spans;
-	b.stats.alg_bytes = 32 * (uint64_t)fe.n_segs + 32 * (uint64_t)n + fe.out_bytes;
+	b.stats.alg_bytes = 32 * (uint64_t)fe.n_segs + 32 * (uint64_t)n + n_pixels;
 	b.out_bytes = (size_t)fe.out_bytes;
 	b.n_main = hdr.n_main;
 	b.span_list = p.span;
@@ -1224,6 +1252,8 @@ int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in
 		f.dat_off = in->dat_off;
 		f.kinds = in->kinds;
 		f.coords = in->coords;
+		f.pbf_pre = in->pbf_pre;
+		f.pbf_fix = in->pbf_fix;
 		f.packed = true;
 	}
 	return fe_submit(ctx, in ? &f : nullptr, out_bitmaps, out_bitmaps ? out_capacity : 0);
@@ -1232,6 +1262,19 @@ int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in
 int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered)
 {
 	return fe_wait(ctx, rects_out, out_bytes, n_segments, rendered);
+}
+
+int vgsdf_outlines_pbf_positions(vgsdf_ctx *ctx, uint64_t *bitmap_at)
+{
+	if (!ctx || !bitmap_at)
+		return VGSDF_E_ARG;
+	if (!ctx->fe || !ctx->fe->prepared || ctx->fe->pend.d_pbf_fix == nullptr) {
+		ctx->err = "vgsdf_outlines_pbf_positions: the last batch was not submitted with pbf_pre / pbf_fix";
+		return VGSDF_E_ARG;
+	}
+	const FePending &p = ctx->fe->pend;
+	std::memcpy(bitmap_at, (const uint8_t *)ctx->fe->h_rects.p + p.at_off, 8 * (size_t)p.n);
+	return VGSDF_OK;
 }
 
 int vgsdf_outlines_render_into(vgsdf_ctx *ctx, const vgsdf_outlines *in, vgsdf_rect *rects_out, uint8_t *out_bitmaps,

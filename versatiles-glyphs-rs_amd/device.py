@@ -39,7 +39,8 @@ class _COutlines(C.Structure):
 
 class _COutlinesPacked(C.Structure):
     _fields_ = [("n_glyphs", C.c_uint32), ("cmd_off", C.c_void_p), ("dat_off", C.c_void_p), ("kinds", C.c_void_p),
-                ("coords", C.c_void_p), ("scale", C.c_void_p), ("shift_x", C.c_void_p)]
+                ("coords", C.c_void_p), ("scale", C.c_void_p), ("shift_x", C.c_void_p),
+                ("pbf_pre", C.c_void_p), ("pbf_fix", C.c_void_p)]  # in-place PBF assembly: NULL = bitmaps packed back to back
 
 
 VGSDF_SYMBOLS = [
@@ -47,7 +48,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
     "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
-    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters",
+    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters", "vgsdf_outlines_pbf_positions",
 ]
 
 _lib = None
@@ -91,6 +92,7 @@ def load_library():
         L.vgsdf_outlines_wait.argtypes = [vp, vp, vp, vp, vp]
         L.vgsdf_outlines_submit_packed.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.vgsdf_outlines_pbf_positions.argtypes = [vp, vp]
         L.vgsdf_add_counters.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
         L.vgsdf_add_counters.restype = None
         L.vgsdf_reset_counters.argtypes = [vp]
@@ -320,8 +322,8 @@ class SdfContext:
         dat_off = at[np.asarray(cmd_off, dtype=np.int64)].astype(np.uint32)
         return dat_off, kinds, coords
 
-    def outlines_submit_packed(self, cmd_off, dat_off, kinds, coords, scale, shift_x, capacity: int):
-        """outlines_submit for the compact upload form (vgsdf_outlines_packed)"""
+    def outlines_submit_packed(self, cmd_off, dat_off, kinds, coords, scale, shift_x, capacity: int, pbf_pre=None, pbf_fix=None):
+        """outlines_submit for the compact upload form (vgsdf_outlines_packed); pbf_pre / pbf_fix: in-place PBF assembly"""
         L = load_library()
         keep = {
             "cmd_off": np.ascontiguousarray(cmd_off, dtype=np.uint32), "dat_off": np.ascontiguousarray(dat_off, dtype=np.uint32),
@@ -334,6 +336,12 @@ class SdfContext:
             raise MemoryError("vgsdf_host_alloc")
         co = _COutlinesPacked(n, keep["cmd_off"].ctypes.data, keep["dat_off"].ctypes.data, keep["kinds"].ctypes.data,
                               keep["coords"].ctypes.data, keep["scale"].ctypes.data, keep["shift"].ctypes.data)
+        if pbf_pre is not None:
+            keep["pbf_pre"] = np.ascontiguousarray(pbf_pre, dtype=np.uint32)
+            co.pbf_pre = keep["pbf_pre"].ctypes.data
+        if pbf_fix is not None:
+            keep["pbf_fix"] = np.ascontiguousarray(pbf_fix, dtype=np.uint8)
+            co.pbf_fix = keep["pbf_fix"].ctypes.data
         rc = L.vgsdf_outlines_submit_packed(self._h, C.byref(co), host, capacity)
         if rc != 0:
             L.vgsdf_host_free(host)
@@ -355,6 +363,12 @@ class SdfContext:
         finally:
             L.vgsdf_host_free(host)
         return rects, out, int(ob.value), int(ns.value)
+
+    def outlines_pbf_positions(self) -> np.ndarray:
+        """after outlines_wait on a batch submitted with pbf_pre / pbf_fix: position of every glyph's bitmap in the arena"""
+        at = np.zeros(self._fe[0], dtype=np.uint64)
+        self._check(load_library().vgsdf_outlines_pbf_positions(self._h, at.ctypes.data))
+        return at
 
     def outlines_render(self) -> np.ndarray:
         """device front-end, step 2: bitmaps of the glyphs with a raster, packed in glyph order"""

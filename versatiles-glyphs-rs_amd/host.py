@@ -47,7 +47,7 @@ VGFONT_SYMBOLS = [
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
     "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
     "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_add_counters",
-    "vg_renderer_reset_counters", "vg_manager_reduced_counters",
+    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf",
 ]
 
 _bound = False
@@ -68,6 +68,8 @@ def _L():
         L.vg_manager_set_threads.argtypes = [vp, C.c_uint, C.c_uint]
         L.vg_manager_set_device_front_end.argtypes = [vp, C.c_int]
         L.vg_manager_set_device_front_end.restype = None
+        L.vg_manager_set_in_place_pbf.argtypes = [vp, C.c_int]
+        L.vg_manager_set_in_place_pbf.restype = None
         L.vg_manager_add_font_with_name.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
         L.vg_manager_add_font_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
         L.vg_manager_add_path.argtypes = [vp, C.c_char_p]
@@ -267,6 +269,10 @@ class FontManager:
 
     def set_threads(self, threads: int = 0, blocks_per_batch: int = 0):
         _L().vg_manager_set_threads(self._h, threads, blocks_per_batch)
+
+    def set_in_place_pbf(self, on: bool):
+        """True (default): the raster stores bitmaps where the finished PBF has them; False: blocks are encoded afterwards"""
+        _L().vg_manager_set_in_place_pbf(self._h, 1 if on else 0)
 
     def set_device_front_end(self, on: bool):
         """flatten / close / scale / bbox on the GPU instead of host threads (HIP renderer only)"""
