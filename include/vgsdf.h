@@ -202,7 +202,14 @@ typedef struct {
 } vgsdf_outlines_packed;
 int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in, uint8_t *out_bitmaps, size_t out_capacity);
 int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
-/* after vgsdf_outlines_wait on a batch submitted with pbf_pre / pbf_fix: bitmap_at[g] = where in the arena the device placed
+/* Between submit and wait: blocks until the front-end's results are on the host — they leave the device right behind the
+ * plan kernel, on a stream of their own, while flattening and raster are still running — and reports the rects and
+ * *out_bytes as vgsdf_outlines_wait will.  *in_place = 1: the raster enqueued with the submission is storing the bitmaps
+ * straight into the caller's page-locked out_bitmaps and nothing else will touch that buffer, so the caller may write the
+ * bytes BETWEEN the bitmaps (in-place PBF assembly: the headers) while it runs; 0: the bitmaps arrive only in
+ * vgsdf_outlines_wait (pageable destination, a capacity guess that did not hold, a batch in error).  Optional. */
+int vgsdf_outlines_peek(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, int *in_place);
+/* after vgsdf_outlines_wait (or _peek) on a batch submitted with pbf_pre / pbf_fix: bitmap_at[g] = where in the arena the device placed
  * glyph g's bitmap (for a glyph without a raster: the byte behind its id field, where the `width` tag goes) */
 int vgsdf_outlines_pbf_positions(vgsdf_ctx *ctx, uint64_t *bitmap_at);
 /* test / inspection: download the segments the front-end produced (seg_off[n_glyphs+1]) */

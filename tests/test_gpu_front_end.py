@@ -403,6 +403,18 @@ def test_in_place_pbf_layout_at_the_c_abi(vg, fira_oracle):
                 poff += px
             pos += int(pre[g]) + 1 + _varint_len(msg) + msg
         assert ob2 == pos and poff == ob
+    # between submit and wait the front-end's results are available while the raster is still running (vgsdf_outlines_peek)
+    c.outlines_submit_packed(cmd_off, dat_off, kinds, coords, scale, shift, 1 << 20, pbf_pre=pre, pbf_fix=fix)
+    r3, ob3, in_place = c.outlines_peek()
+    assert r3.tobytes() == rects.tobytes() and ob3 == ob2 and in_place  # page-locked destination, capacities held
+    assert c.outlines_pbf_positions().tobytes() == at.tobytes()
+    r4, arena4, ob4, _ = c.outlines_wait()
+    assert r4.tobytes() == rects.tobytes() and ob4 == ob2 and arena4 is not None
+    c.outlines_submit_packed(cmd_off, dat_off, kinds, coords, scale, shift, 64, pbf_pre=pre, pbf_fix=fix)
+    assert c.outlines_peek()[2] is False                                # the arena does not fit: bitmaps only after the wait
+    c.outlines_wait()
+    with pytest.raises(vg.VgsdfError, match="nothing was submitted"):
+        c.outlines_peek()
     with pytest.raises(vg.VgsdfError, match="pbf_pre"):
         c.outlines_submit_packed(cmd_off, dat_off, kinds, coords, scale, shift, 1 << 20, pbf_pre=pre)
     ref.close()

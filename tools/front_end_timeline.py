@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Timeline of the LAST end-to-end render in a tools/profile_front_end.sh trace: start (relative to the first activity of
+that render), duration and gap of every copy and kernel, in device time.   python tools/front_end_timeline.py <tag>"""
+import csv
+import glob
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+src = ROOT / "gpurun_out" / f"prof_{sys.argv[1]}_front_end"
+ev = []
+for pat, name_key in (("trace/**/*kernel_trace.csv", "Kernel_Name"), ("trace/**/*memory_copy_trace.csv", "Direction")):
+    files = sorted(glob.glob(str(src / pat), recursive=True), key=os.path.getmtime)
+    if files:
+        for r in csv.DictReader(open(files[-1])):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_key][:60]))
+ev.sort()
+# the last render = the events after the last gap of more than 200 us
+start = 0
+for i in range(1, len(ev)):
+    if ev[i][0] - ev[i - 1][1] > 200_000:
+        start = i
+run = ev[start:]
+t0 = run[0][0]
+prev_end = t0
+print(f"{'start us':>9} {'dur us':>8} {'gap us':>7}  activity")
+for s, e, n in run:
+    print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:7.1f}  {n}")
+    prev_end = max(prev_end, e)
+print(f"span {(prev_end - t0) / 1e3:.1f} us, busy {sum(e - s for s, e, _ in run) / 1e3:.1f} us")

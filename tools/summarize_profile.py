@@ -54,6 +54,13 @@ for sub in ("fetch", "write", "sq", "sq2", "sq3", "sq4"):
     allc.update(pmc(sub))
 for k, v in sorted(allc.items()):
     lines.append(f"* {k} = {v:.6g}")
+if "SQ_LDS_BANK_CONFLICT" in allc and allc.get("SQ_ACTIVE_INST_LDS"):
+    lines += ["", f"LDS bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = **{allc['SQ_LDS_BANK_CONFLICT'] / allc['SQ_ACTIVE_INST_LDS']:.2f}** "
+              "of the LDS-active cycles"]
+if "GRBM_GUI_ACTIVE" in allc:
+    lines += ["", f"GRBM_GUI_ACTIVE / 8 XCDs = {allc['GRBM_GUI_ACTIVE'] / 8:.0f} cycles per launch (MI355X_MICROARCH.md, DVFS give-back: / kernel wall "
+              "time = effective clock; reads high on dispatches this short — the clock a VALU-bound kernel holds is measured by "
+              "tools/ubench/clock_probe.hip)"]
 traffic = None
 if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
     # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads 1/2
@@ -66,7 +73,7 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
     d = json.loads(tj.read_text()) if tj.exists() else {}
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("sdf_kernels.hip", "sdf_kernels.h"):
+    for f in ("sdf_kernels.hip", "sdf_span_kernel.inc", "sdf_kernels.h"):
         hsh.update((ROOT / "versatiles-glyphs-rs_amd" / "csrc" / f).read_bytes())
     ent = {"bytes_per_launch": traffic, "fetch_kib": allc["FETCH_SIZE"],
            "write_kib": allc["WRITE_SIZE"], "profile": f"profiles/{tag}_summary.md",

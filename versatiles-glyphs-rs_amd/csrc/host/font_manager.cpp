@@ -975,23 +975,22 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 // G.out, laid out by outline_plan from pbf_pre / pbf_fix); what is left is the ~20 bytes around each bitmap and the
 // block headers, written here on the pool.  A block without a glyph of this group is encoded on its own (32 bytes).
 // Every position the device reports is checked against this side's own arithmetic.
-void FontManager::fe_assemble_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer)
+void FontManager::fe_assemble(const std::vector<Todo> &tasks, FeGroup &G)
 {
 	ThreadPool &tp = pool();
 	const double t3 = now_s();
 	const size_t nb = G.g1 - G.g0;
 	MergedOutlines &m = G.m;
-	struct Piece {
-		const uint8_t *p = nullptr;
-		size_t n = 0;
-	};
-	std::vector<Piece> piece(nb);
+	using Piece = FeGroup::Piece;
+	std::vector<Piece> &piece = G.piece;
+	piece.assign(nb, Piece{});
 	// blocks without a glyph of this group (211 of a font's 256, typically): name + range only, ~35 bytes each, written
 	// into one store — a vector per file cost more than all the header bytes of the font together
 	size_t small_stride = 0;
 	for (size_t i = 0; i < nb; i++)
 		small_stride = std::max(small_stride, tasks[G.g0 + i].name->size() + 48);
-	std::vector<uint8_t> small(nb * small_stride);
+	std::vector<uint8_t> &small = G.small;
+	small.resize(nb * small_stride);
 	std::atomic<uint64_t> n_raster{0}, n_pixels{0};
 	std::atomic<bool> mismatch{false};
 	uint8_t *arena = G.out.data();
@@ -1041,17 +1040,24 @@ void FontManager::fe_assemble_write(const std::vector<Todo> &tasks, FeGroup &G, 
 	});
 	if (mismatch)
 		throw std::runtime_error("in-place PBF assembly: the device's layout of the arena differs from the host's");
+	G.n_raster = n_raster;
+	G.n_pixels = n_pixels;
+	timings_.encode_s += now_s() - t3;
+}
+
+void FontManager::fe_write_pieces(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer)
+{
 	const double t4 = now_s();
-	timings_.encode_s += t4 - t3;
+	const size_t nb = G.g1 - G.g0;
 	for (size_t i = 0; i < nb; i++) {
-		writer.write_bytes(*tasks[G.g0 + i].name + "/" + tasks[G.g0 + i].block.filename(), piece[i].p, piece[i].n);
-		timings_.pbf_bytes += piece[i].n;
+		writer.write_bytes(*tasks[G.g0 + i].name + "/" + tasks[G.g0 + i].block.filename(), G.piece[i].p, G.piece[i].n);
+		timings_.pbf_bytes += G.piece[i].n;
 	}
 	timings_.write_s += now_s() - t4;
 	timings_.blocks += nb;
 	timings_.glyphs += G.n_jobs;
-	timings_.rasters += n_raster;
-	timings_.pixels += n_pixels;
+	timings_.rasters += G.n_raster;
+	timings_.pixels += G.n_pixels;
 	timings_.segments += G.n_segs;
 }
 
@@ -1163,18 +1169,31 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 	};
 	auto collect = [&](size_t k) {
 		FeGroup &G = fe_group_[k & 1];
-		const double t = now_s();
+		double t = now_s();
 		G.rects.clear();
 		G.out_bytes = G.n_segs = 0;
+		// in-place assembly: the rects come back right behind the plan kernel, a good 100 us before the bitmaps — the
+		// headers are written while the raster is still storing the bitmaps between them
+		bool early = false;
+		if (in_flight[k & 1] && G.in_place && G.n_jobs) {
+			early = renderer.peek_outlines((int)(k & 1), G.rects, G.out_bytes, G.n_jobs, &G.pbf_at);
+			timings_.device_s += now_s() - t;
+			if (early)
+				fe_assemble(tasks, G);
+			t = now_s();
+		}
 		if (in_flight[k & 1]) {
 			in_flight[k & 1] = false;
 			renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs, G.in_place ? &G.pbf_at : nullptr);
 		}
 		timings_.device_s += now_s() - t;
-		if (G.in_place && G.n_jobs)
-			fe_assemble_write(tasks, G, writer);
-		else
+		if (G.in_place && G.n_jobs) {
+			if (!early)
+				fe_assemble(tasks, G);
+			fe_write_pieces(tasks, G, writer);
+		} else {
 			fe_encode_write(tasks, G, writer);
+		}
 	};
 	try {
 		for (size_t k = 0; k < groups.size(); k++) {

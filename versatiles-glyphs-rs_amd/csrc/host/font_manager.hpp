@@ -264,6 +264,13 @@ private:
 		std::vector<uint64_t> pbf_at;       // in-place assembly: position of every job's bitmap in `out`
 		std::vector<uint32_t> task_g0;      // first job of every task of the group (+ one past the last)
 		bool in_place = false;
+		struct Piece { // a finished block file: inside `out` (assembled in place) or inside `small`
+			const uint8_t *p = nullptr;
+			size_t n = 0;
+		};
+		std::vector<Piece> piece;
+		std::vector<uint8_t> small; // blocks without a glyph of the group: name + range only
+		uint64_t n_raster = 0, n_pixels = 0;
 		HostBuffer<uint8_t> out{true};
 		uint64_t out_bytes = 0, n_segs = 0;
 		uint32_t n_jobs = 0;
@@ -271,7 +278,8 @@ private:
 	FeGroup fe_group_[2]; // two groups in flight: one on the GPU, one being recorded / encoded
 	void fe_record(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
-	void fe_assemble_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
+	void fe_assemble(const std::vector<Todo> &tasks, FeGroup &G);
+	void fe_write_pieces(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
 	bool in_place_pbf_ = true;
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here

@@ -326,6 +326,27 @@ void Renderer::submit_outlines(int lane, const vgsdf_outlines_packed &v, HostBuf
 	}
 }
 
+bool Renderer::peek_outlines(int lane, std::vector<vgsdf_rect> &rects, uint64_t &out_bytes, uint32_t n_glyphs,
+                             std::vector<uint64_t> *pbf_at) const
+{
+	lane &= 1;
+	vgsdf_ctx *c = lane == 0 ? ctx_ : ctx2_;
+	rects.assign(n_glyphs, vgsdf_rect{});
+	out_bytes = 0;
+	int in_place = 0;
+	std::unique_lock<std::mutex> lock(mu_, std::defer_lock);
+	if (lane == 0)
+		lock.lock();
+	if (vgsdf_outlines_peek(c, rects.data(), &out_bytes, &in_place) != VGSDF_OK)
+		throw std::runtime_error(std::string("vgsdf_outlines_peek: ") + vgsdf_last_error(c));
+	if (in_place && pbf_at) {
+		pbf_at->assign(n_glyphs, 0);
+		if (n_glyphs && vgsdf_outlines_pbf_positions(c, pbf_at->data()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_pbf_positions: ") + vgsdf_last_error(c));
+	}
+	return in_place != 0;
+}
+
 void Renderer::wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
                              uint64_t &n_segments, uint32_t n_glyphs, std::vector<uint64_t> *pbf_at) const
 {

@@ -298,6 +298,11 @@ public:
 	void submit_outlines(int lane, const vgsdf_outlines_packed &batch, HostBuffer<uint8_t> &out) const;
 	void wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
 	                   uint64_t &n_segments, uint32_t n_glyphs, std::vector<uint64_t> *pbf_at = nullptr) const;
+	// Between the two: the front-end's results as soon as they are on the host, while the raster is still running
+	// (vgsdf_outlines_peek).  Returns true when the raster is storing the bitmaps straight into `out` as it stands, so
+	// that the caller may write the bytes between them (in-place PBF assembly) right away.
+	bool peek_outlines(int lane, std::vector<vgsdf_rect> &rects, uint64_t &out_bytes, uint32_t n_glyphs,
+	                   std::vector<uint64_t> *pbf_at = nullptr) const;
 
 	// Device half for a packed batch: fills out[batch.out_bytes()].  Hip: one
 	// vgsdf_render_batch call; Dummy: zeros (renderer_dummy.rs).  Throws std::runtime_error.

@@ -27,6 +27,7 @@
 // lane with a 32-point curve (36 + 45 us per Noto Sans Regular font; now 7 + 21), and a wave-per-glyph form
 // measured 2.5x slower still.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "outline_kernels.h"
@@ -923,10 +924,8 @@ __device__ __forceinline__ unsigned long long block_exclusive_sum(unsigned long 
 // bytes of a protobuf varint
 __device__ __forceinline__ uint32_t varint_len(unsigned long long v)
 {
-	uint32_t n = 1;
-	for (; v >= 0x80; v >>= 7)
-		n++;
-	return n;
+	const uint32_t bits = 64u - (uint32_t)__builtin_clzll(v | 1ull); // 1 .. 64 significant bits, 7 per byte
+	return (bits + 6u) / 7u;
 }
 
 // In-place PBF assembly (vgsdf.h, vgsdf_outlines_packed::pbf_pre / pbf_fix): what glyph `r` occupies in the arena of
@@ -1006,7 +1005,9 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	// a run of up to eight glyphs (batches of <= 8192 glyphs: every group the dispatcher forms) stays in registers with its classification, so
 	// the rects are read once and classified once for both passes
 	constexpr uint32_t kKeep = 8;
-	const bool kept = per <= kKeep;
+	// (in-place PBF assembly takes the re-reading loops: eight inlined placements in the unrolled ones spill the kernel —
+	// one 1024-thread workgroup, 128 VGPRs per lane — to scratch: 21 -> 26 us, against 13 us without the feature)
+	const bool kept = per <= kKeep && pbf_fix == nullptr;
 	OutlineRect kr[kKeep];
 	uint32_t kcls[kKeep], kT[kKeep], kn[kKeep], kw[kKeep];
 #pragma unroll
@@ -1037,8 +1038,11 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 		if (kept) {
 #pragma unroll
 			for (uint32_t j = 0; j < kKeep; j++)
-				if (g_lo + j < g_hi)
-					sum_one(g_lo + j, kr[j]);
+				if (kr[j].has_raster) { // (absent glyphs: zero rects)
+					my_s += kr[j].n_segments;
+					my_p += (unsigned long long)kr[j].w * kr[j].h;
+					bad |= (unsigned long long)kr[j].w * kr[j].h > 0xFFFFFFFFull - 256ull;
+				}
 		} else {
 			for (uint32_t g = g_lo; g < g_hi; g++)
 				sum_one(g, rects[g]);
@@ -1050,7 +1054,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 			s_carry[0] = tot_s;
 			s_carry[1] = tot_p;
 		}
-		auto desc_one = [&](uint32_t g, const OutlineRect &r, uint32_t cls, uint32_t nspans, uint32_t weight) {
+		auto desc_one = [&](uint32_t g, const OutlineRect &r, uint32_t cls, uint32_t nspans, uint32_t weight, auto in_place) {
 			const unsigned long long px = r.has_raster ? (unsigned long long)r.w * r.h : 0ull;
 			const unsigned long long segs = r.has_raster ? r.n_segments : 0u;
 			GlyphDesc d;
@@ -1060,7 +1064,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 			d.y0 = r.y0;
 			d.w = r.has_raster ? r.w : 0;
 			d.h = r.has_raster ? r.h : 0;
-			if (pbf_fix != nullptr) {
+			if (decltype(in_place)::value && pbf_fix != nullptr) {
 				unsigned long long at;
 				const unsigned long long took = pbf_place(r, pbf_pre[g], pbf_fix[g], at);
 				d.out_off = po + at; // the raster stores the bitmap where the finished file has it
@@ -1079,13 +1083,13 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 #pragma unroll
 			for (uint32_t j = 0; j < kKeep; j++)
 				if (g_lo + j < g_hi)
-					desc_one(g_lo + j, kr[j], kcls[j], kn[j], kw[j]);
+					desc_one(g_lo + j, kr[j], kcls[j], kn[j], kw[j], std::false_type{});
 		} else {
 			for (uint32_t g = g_lo; g < g_hi; g++) {
 				const OutlineRect r = rects[g];
 				uint32_t cls, T, nspans, weight;
 				classify(r, cls, T, nspans, weight);
-				desc_one(g, r, cls, nspans, weight);
+				desc_one(g, r, cls, nspans, weight, std::true_type{});
 			}
 		}
 	}

@@ -63,7 +63,9 @@ inline void *pinned_device_ptr(void *p, size_t bytes)
 struct vgsdf_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t copy_stream = nullptr;                 // the front-end's read-back, beside the kernels that follow the plan
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t ev_plan = nullptr, ev_rects = nullptr;   // plan done (kernel stream) / rects on the host (copy stream)
 	int variant = 0;
 	std::string err;
 	// grow-only scratch of vgsdf_render_batch: no hipMalloc / hipHostMalloc in steady state
@@ -152,6 +154,7 @@ struct FrontEnd {
 	uint64_t out_bytes = 0;
 	vgsdf_dbatch batch; // borrowed view over the buffers above
 	bool prepared = false;
+	bool peeked = false; // vgsdf_outlines_peek has waited for the read-back of the pending submission
 	FrontEnd()
 	{
 		h_rects.host = true;
@@ -213,6 +216,9 @@ int vgsdf_create(int device_ordinal, vgsdf_ctx **out)
 	ctx->device = device_ordinal;
 	if ((e = hipSetDevice(device_ordinal)) != hipSuccess ||
 	    (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&ctx->ev_plan, hipEventDisableTiming)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&ctx->ev_rects, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
 		g_create_error = std::string("vgsdf_create: ") + hipGetErrorString(e);
 		vgsdf_destroy(ctx);
@@ -231,6 +237,14 @@ void vgsdf_destroy(vgsdf_ctx *ctx)
 		(void)hipStreamSynchronize(ctx->stream);
 		(void)hipStreamDestroy(ctx->stream);
 	}
+	if (ctx->copy_stream) {
+		(void)hipStreamSynchronize(ctx->copy_stream);
+		(void)hipStreamDestroy(ctx->copy_stream);
+	}
+	if (ctx->ev_plan)
+		(void)hipEventDestroy(ctx->ev_plan);
+	if (ctx->ev_rects)
+		(void)hipEventDestroy(ctx->ev_rects);
 	if (ctx->ev0)
 		(void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1)
@@ -927,6 +941,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		return VGSDF_E_ARG;
 	}
 	fe.prepared = false;
+	fe.peeked = false;
 	fe.n_glyphs = n;
 	fe.n_cmds = n_cmds;
 	fe.n_segs = 0;
@@ -990,6 +1005,8 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	FE_TRY(fe_ensure_tiles(fe, 2 * (size_t)n + 1024));
 	FE_TRY(fe_ensure_segs(fe, 12 * (size_t)n_cmds + 4096, n));
 
+	if (std::getenv("VGSDF_TRACE") != nullptr)
+		FE_TRY(hipEventRecord(ctx->ev0, st));
 	const uint8_t *d_kinds = nullptr;
 	const float *d_coords = nullptr;
 	if (blob) {
@@ -1058,12 +1075,29 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d.rects,
 	                              (uint32_t *)fe.flag.p, st));
 	FE_KERNEL(fe_launch_plan(ctx, fe, p.launch_spans));
+	// The front-end's results (rects, totals, positions of the bitmaps) are final once the plan has run: they travel back
+	// on a stream of their own, beside the flattening and the raster instead of behind them — the host can have them a
+	// good 100 us before the bitmaps (vgsdf_outlines_peek), and the end of the submission loses a copy and its hand-over.
+	static const char *early_env = std::getenv("VGSDF_EARLY_COPY"); // (measurement switch: 0 = read-back behind the raster, as in round 2)
+	const bool early_copy = !(early_env && early_env[0] == '0');
+	if (early_copy) {
+		FE_TRY(hipEventRecord(ctx->ev_plan, st));
+		FE_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_plan, 0));
+		FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, p.rh_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+		FE_TRY(hipEventRecord(ctx->ev_rects, ctx->copy_stream));
+	}
 	FE_KERNEL(fe_launch_emit(ctx, fe));
 	if (p.spec)
 		FE_KERNEL(vgsdf_launch_span_planned(d.descs, (const uint2 *)fe.tiles.p, p.launch_spans, (const double *)fe.seg.p,
 		                                    (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2, (const double *)fe.seg.p + 3, 4,
 		                                    p.d_spec, fe.boxes.p, d.hdr, st));
-	FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, p.rh_bytes, hipMemcpyDeviceToHost, st));
+	if (!early_copy) {
+		FE_TRY(hipMemcpyAsync(fe.h_rects.p, fe.rects_hdr.p, p.rh_bytes, hipMemcpyDeviceToHost, st));
+		FE_TRY(hipEventRecord(ctx->ev_rects, st));
+	}
+	static const bool trace_span = std::getenv("VGSDF_TRACE") != nullptr;
+	if (trace_span)
+		FE_TRY(hipEventRecord(ctx->ev1, st));
 	p.active = true;
 	return VGSDF_OK;
 }
@@ -1099,7 +1133,8 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	}
 	(void)hipSetDevice(ctx->device);
 	hipStream_t st = ctx->stream;
-	FE_TRY(hipStreamSynchronize(st)); // the one read-back of the front-end
+	FE_TRY(hipStreamSynchronize(st)); // the one synchronisation of the submission
+	FE_TRY(hipEventSynchronize(ctx->ev_rects)); // (the read-back finished long ago: it left right behind the plan)
 	const double tr2 = fe_now();
 	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
 	vgsdf::PlanHeader hdr;
@@ -1194,6 +1229,13 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 		if (rendered)
 			*rendered = 1;
 	}
+	if (trace) {
+		float span_ms = 0;
+		if (hipEventElapsedTime(&span_ms, ctx->ev0, ctx->ev1) == hipSuccess)
+			std::fprintf(stderr, "[vgsdf] device span of the submission (upload ... last kernel, events on the kernel stream): %.1f us\n", span_ms * 1e3);
+		else
+			(void)hipGetLastError();
+	}
 	if (trace && p.spec_out)
 		std::fprintf(stderr, "[vgsdf] one submission%s, %s destination\n", done ? "" : " (guess too small: second launches)",
 		             p.spec_direct ? "page-locked" : "pageable");
@@ -1264,11 +1306,45 @@ int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_byt
 	return fe_wait(ctx, rects_out, out_bytes, n_segments, rendered);
 }
 
+int vgsdf_outlines_peek(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, int *in_place)
+{
+	if (out_bytes)
+		*out_bytes = 0;
+	if (in_place)
+		*in_place = 0;
+	if (!ctx)
+		return VGSDF_E_ARG;
+	if (!ctx->fe || !ctx->fe->pend.active) {
+		ctx->err = "vgsdf_outlines_peek: nothing was submitted";
+		return VGSDF_E_ARG;
+	}
+	FrontEnd &fe = *ctx->fe;
+	const FePending &p = fe.pend;
+	if (p.n == 0)
+		return VGSDF_OK;
+	if (!rects_out) {
+		ctx->err = "vgsdf_outlines: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	(void)hipSetDevice(ctx->device);
+	FE_TRY(hipEventSynchronize(ctx->ev_rects));
+	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)p.n);
+	vgsdf::PlanHeader hdr;
+	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + p.hdr_off, sizeof hdr);
+	if (out_bytes)
+		*out_bytes = hdr.out_bytes;
+	// the raster behind the plan runs over the whole list and stores through the caller's own (page-locked) buffer
+	if (in_place)
+		*in_place = p.spec && p.spec_direct && hdr.ok != 0 && hdr.error == 0;
+	fe.peeked = true;
+	return VGSDF_OK;
+}
+
 int vgsdf_outlines_pbf_positions(vgsdf_ctx *ctx, uint64_t *bitmap_at)
 {
 	if (!ctx || !bitmap_at)
 		return VGSDF_E_ARG;
-	if (!ctx->fe || !ctx->fe->prepared || ctx->fe->pend.d_pbf_fix == nullptr) {
+	if (!ctx->fe || !(ctx->fe->prepared || (ctx->fe->pend.active && ctx->fe->peeked)) || ctx->fe->pend.d_pbf_fix == nullptr) {
 		ctx->err = "vgsdf_outlines_pbf_positions: the last batch was not submitted with pbf_pre / pbf_fix";
 		return VGSDF_E_ARG;
 	}

@@ -48,7 +48,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
     "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
-    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters", "vgsdf_outlines_pbf_positions",
+    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters", "vgsdf_outlines_pbf_positions", "vgsdf_outlines_peek",
 ]
 
 _lib = None
@@ -93,6 +93,7 @@ def load_library():
         L.vgsdf_outlines_submit_packed.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
         L.vgsdf_outlines_pbf_positions.argtypes = [vp, vp]
+        L.vgsdf_outlines_peek.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.vgsdf_add_counters.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
         L.vgsdf_add_counters.restype = None
         L.vgsdf_reset_counters.argtypes = [vp]
@@ -348,6 +349,16 @@ class SdfContext:
             self._check(rc)
         self._inflight = (keep, host, capacity, n)
 
+    def outlines_peek(self):
+        """between submit and wait: the front-end's results while the raster is still running -> (rects, out_bytes, in_place)"""
+        ob, ip = C.c_uint64(0), C.c_int(0)
+        if getattr(self, "_inflight", None) is None:  # (the library says so)
+            self._check(load_library().vgsdf_outlines_peek(self._h, None, C.byref(ob), C.byref(ip)))
+        keep, host, capacity, n = self._inflight
+        rects = np.zeros(n, dtype=RECT_DTYPE)
+        self._check(load_library().vgsdf_outlines_peek(self._h, rects.ctypes.data, C.byref(ob), C.byref(ip)))
+        return rects, int(ob.value), bool(ip.value)
+
     def outlines_wait(self):
         """second half -> (rects, bitmaps | None, out_bytes, n_segments)"""
         L = load_library()
@@ -366,7 +377,7 @@ class SdfContext:
 
     def outlines_pbf_positions(self) -> np.ndarray:
         """after outlines_wait on a batch submitted with pbf_pre / pbf_fix: position of every glyph's bitmap in the arena"""
-        at = np.zeros(self._fe[0], dtype=np.uint64)
+        at = np.zeros(self._inflight[3] if getattr(self, "_inflight", None) else self._fe[0], dtype=np.uint64)
         self._check(load_library().vgsdf_outlines_pbf_positions(self._h, at.ctypes.data))
         return at
 
