@@ -108,9 +108,20 @@ std::unique_ptr<FontFileEntry> FontFileEntry::create(std::vector<uint8_t> data, 
 	return e;
 }
 
-std::string GlyphBlock::range() const
+const std::string &GlyphBlock::range() const
 {
-	return std::to_string(start_index) + "-" + std::to_string(start_index + GLYPH_BLOCK_SIZE - 1);
+	// "{start}-{start + 255}" (glyph_block.rs:53-59); start is a multiple of 256 below 65536 (wrapper.rs:55-60)
+	static const std::vector<std::string> table = [] {
+		std::vector<std::string> t;
+		for (uint32_t s = 0; s < 0x10000; s += GLYPH_BLOCK_SIZE)
+			t.push_back(std::to_string(s) + "-" + std::to_string(s + GLYPH_BLOCK_SIZE - 1));
+		return t;
+	}();
+	static thread_local std::string other;
+	if (start_index % GLYPH_BLOCK_SIZE == 0 && start_index < 0x10000)
+		return table[start_index / GLYPH_BLOCK_SIZE];
+	other = std::to_string(start_index) + "-" + std::to_string(start_index + GLYPH_BLOCK_SIZE - 1);
+	return other;
 }
 
 void GlyphBlock::prepare(TessScratch &scratch, GlyphBatch &batch, uint32_t ci0, uint32_t ci1) const
@@ -899,7 +910,7 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 	G.slice_dat.resize(slices.size());
 	for (size_t i = 0; i < slices.size(); i++) {
 		OSlice &s = slices[i];
-		const OutlineBatch &l = workers_[s.worker].olocal;
+		const PackedOutlineBatch &l = workers_[s.worker].olocal;
 		s.g_job = n_jobs;
 		G.slice_cmd[i] = n_cmds;
 		G.slice_dat[i] = n_floats;
@@ -924,31 +935,13 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 	m.dat_off[0] = 0;
 	tp.run(slices.size(), [&](size_t i, unsigned) {
 		const OSlice &s = slices[i];
-		const OutlineBatch &l = workers_[s.worker].olocal;
-		const uint32_t lc0 = l.cmd_off[s.job0], lc1 = l.cmd_off[s.job1], ld0 = l.dat_off[s.job0];
-		uint8_t *kinds = m.kinds + G.slice_cmd[i];
-		float *co = m.coords + G.slice_dat[i];
-		for (uint32_t c = lc0; c < lc1; c++) {
-			const vgsdf_outline_cmd &q = l.cmds[c];
-			*kinds++ = (uint8_t)q.kind;
-			switch (q.kind) {
-			case 0:
-			case 1:
-				co[0] = q.x, co[1] = q.y;
-				co += 2;
-				break;
-			case 2:
-				co[0] = q.x1, co[1] = q.y1, co[2] = q.x, co[3] = q.y;
-				co += 4;
-				break;
-			case 3:
-				co[0] = q.x1, co[1] = q.y1, co[2] = q.x2, co[3] = q.y2, co[4] = q.x, co[5] = q.y;
-				co += 6;
-				break;
-			default:
-				break;
-			}
-		}
+		const PackedOutlineBatch &l = workers_[s.worker].olocal;
+		const uint32_t lc0 = l.cmd_off[s.job0], lc1 = l.cmd_off[s.job1], ld0 = l.dat_off[s.job0], ld1 = l.dat_off[s.job1];
+		// (the workers record in the upload form itself: merging is a copy)
+		if (lc1 > lc0)
+			std::memcpy(m.kinds + G.slice_cmd[i], l.kinds.data() + lc0, lc1 - lc0);
+		if (ld1 > ld0)
+			std::memcpy(m.coords + G.slice_dat[i], l.coords.data() + ld0, sizeof(float) * (ld1 - ld0));
 		for (uint32_t j = s.job0; j < s.job1; j++) {
 			const uint32_t g = s.g_job + (j - s.job0);
 			m.jobs[g] = l.jobs[j];
@@ -998,7 +991,7 @@ void FontManager::fe_assemble(const std::vector<Todo> &tasks, FeGroup &G)
 		const Todo &td = tasks[G.g0 + i];
 		const uint32_t a = G.task_g0[i], b = G.task_g0[i + 1];
 		if (a == b) {
-			const std::string range = td.block.range();
+			const std::string &range = td.block.range();
 			uint8_t *entries = small.data() + i * small_stride + kPbfHeadRoom + pbf_block_fields(td.name->size(), range.size());
 			uint8_t *file = write_pbf_block_header(entries, *td.name, range, 0);
 			piece[i] = Piece{file, (size_t)(entries - file)};
@@ -1049,8 +1042,10 @@ void FontManager::fe_write_pieces(const std::vector<Todo> &tasks, FeGroup &G, Wr
 {
 	const double t4 = now_s();
 	const size_t nb = G.g1 - G.g0;
+	std::string path;
 	for (size_t i = 0; i < nb; i++) {
-		writer.write_bytes(*tasks[G.g0 + i].name + "/" + tasks[G.g0 + i].block.filename(), G.piece[i].p, G.piece[i].n);
+		tasks[G.g0 + i].block.path_into(*tasks[G.g0 + i].name, path);
+		writer.write_bytes(path, G.piece[i].p, G.piece[i].n);
 		timings_.pbf_bytes += G.piece[i].n;
 	}
 	timings_.write_s += now_s() - t4;
@@ -1132,16 +1127,17 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 	const double t_start = now_s();
 	(void)pool();
 	// Group size: every group costs ~0.1 ms of device latency and three fork/joins of the host pool, so small fonts
-	// are grouped (21 fixture fonts: 12.9 ms one font per group, 3.3 ms in one group) and a run is cut into several
-	// groups — to overlap host and device — only when each keeps >= 3500 glyphs (measured: the 14 180 glyphs of the 21
-	// fixture fonts 3.3 ms in one group, 2.8 ms in four; Noto Sans' 6445 glyphs 1.7 ms in one, 2.2 ms in four).
+	// are grouped (21 fixture fonts: 12.9 ms one font per group, 2.1 ms in one group) and a run is cut into several
+	// groups — to overlap host and device — only when each keeps >= 5000 glyphs (measured in round 3, 32 threads on a
+	// 16-CPU quota: the 14 180 glyphs of the 21 fixture fonts 2.5 / 2.1 / 1.8 / 2.0 / 2.1 ms with groups of at least
+	// 2000 / 3500 / 5000 / 8000 / 20 000 glyphs; Noto Sans' 6445 glyphs 1.14 / 1.09 / 1.07 ms at 2000 / 5000 / 20 000).
 	// An explicit set_batch_blocks() bounds the group in blocks instead.
 	size_t total_glyphs = 0;
 	for (const Todo &t : tasks)
 		total_glyphs += t.block.len();
 	constexpr size_t kFeGlyphBudget = 32768;
 	static const char *mg = std::getenv("VG_FE_MIN_GROUP"); // (measurement switch)
-	const size_t kFeMinGroup = mg ? (size_t)std::max(1, std::atoi(mg)) : 3500;
+	const size_t kFeMinGroup = mg ? (size_t)std::max(1, std::atoi(mg)) : 5000;
 	const size_t n_groups = std::max<size_t>(1, total_glyphs / kFeMinGroup);
 	const size_t budget = std::min(kFeGlyphBudget, (total_glyphs + n_groups - 1) / n_groups);
 	std::vector<std::pair<size_t, size_t>> groups;
@@ -1330,8 +1326,10 @@ void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Rend
 		const double t3 = now_s();
 		timings_.encode_s += t3 - t2;
 
+		std::string path;
 		for (size_t i = 0; i < nb; i++) {
-			writer.write_bytes(*tasks[g0 + i].name + "/" + tasks[g0 + i].block.filename(), piece[i].p, piece[i].n);
+			tasks[g0 + i].block.path_into(*tasks[g0 + i].name, path);
+			writer.write_bytes(path, piece[i].p, piece[i].n);
 			timings_.pbf_bytes += piece[i].n;
 		}
 		timings_.write_s += now_s() - t3;

@@ -71,8 +71,16 @@ struct GlyphBlock {
 	}
 	size_t len() const { return count; }
 	bool is_empty() const { return count == 0; }
-	std::string range() const; // glyph_block.rs:53-59
+	const std::string &range() const; // glyph_block.rs:53-59 (the 256 strings of the BMP blocks are built once)
 	std::string filename() const { return range() + ".pbf"; } // :85-87
+	// "<font>/<range>.pbf" into a caller-owned string (its capacity is reused: one task of a run after the other)
+	void path_into(const std::string &font, std::string &out) const
+	{
+		out.assign(font);
+		out.push_back('/');
+		out += range();
+		out += ".pbf";
+	}
 
 	// Host half of GlyphBlock::render (glyph_block.rs:72-77), glyphs in ascending id;
 	// [ci0, ci1) restricts it to a sub-range of the block's 256 code points.
@@ -217,7 +225,7 @@ private:
 	struct alignas(128) Worker { // own cache lines: the vector headers inside are written per glyph
 		TessScratch scratch;
 		GlyphBatch local;
-		OutlineBatch olocal;
+		PackedOutlineBatch olocal;
 		char pad[128];
 	};
 	// One process, N devices (renderer.n_devices() > 1): the glyphs of every font are dealt to the device lanes by

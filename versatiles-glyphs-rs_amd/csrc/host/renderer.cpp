@@ -295,6 +295,29 @@ bool Renderer::record(const Face &face, uint32_t index, OutlineBatch &batch)
 	return true;
 }
 
+bool Renderer::record(const Face &face, uint32_t index, PackedOutlineBatch &batch)
+{
+	if (index > 0x10FFFF || (index >= 0xD800 && index <= 0xDFFF)) // renderer.rs:104
+		return false;
+	const auto glyph_id = face.glyph_index(index); // :106
+	if (!glyph_id)
+		return false;
+	const double scale = (double)GLYPH_SIZE / (double)face.units_per_em(); // :107
+	PackedRecorder rec(batch.kinds, batch.coords);
+	face.outline_glyph(*glyph_id, rec); // :109-111, callbacks only
+	const double advance_float = (double)face.glyph_hor_advance(*glyph_id).value_or(0) * scale * 0.95; // :115
+	const uint32_t advance = to_u32(std::round(advance_float));                                          // :116
+	GlyphJob job;
+	job.id = index;
+	job.advance = advance;
+	batch.jobs.push_back(job);
+	batch.cmd_off.push_back((uint32_t)batch.kinds.size());
+	batch.dat_off.push_back((uint32_t)batch.coords.size());
+	batch.scale.push_back(scale);
+	batch.shift_x.push_back(((double)advance - advance_float) / 2.0); // :130
+	return true;
+}
+
 vgsdf_ctx *Renderer::lane_ctx(int lane) const
 {
 	if (lane == 0)

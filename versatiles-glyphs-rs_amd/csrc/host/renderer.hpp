@@ -174,6 +174,47 @@ struct OutlineBatch {
 	}
 };
 
+// The same, recorded straight in the compact upload form of vgsdf_outlines_packed (one kind byte per command plus only
+// the coordinates its kind carries: ~12 bytes per command of a TrueType font instead of a 28-byte record): what the
+// workers of FontManager write, so that merging their batches is a copy.
+struct PackedOutlineBatch {
+	std::vector<GlyphJob> jobs;
+	std::vector<uint32_t> cmd_off{0}, dat_off{0}; // [jobs + 1] into kinds / coords
+	std::vector<uint8_t> kinds;
+	std::vector<float> coords;
+	std::vector<double> scale, shift_x;
+	void clear()
+	{
+		jobs.clear();
+		cmd_off.assign(1, 0);
+		dat_off.assign(1, 0);
+		kinds.clear();
+		coords.clear();
+		scale.clear();
+		shift_x.clear();
+	}
+};
+
+// OutlineBuilder sink for it
+class PackedRecorder final : public OutlineBuilder {
+public:
+	PackedRecorder(std::vector<uint8_t> &kinds, std::vector<float> &coords) : kinds_(kinds), coords_(coords) {}
+	void move_to(float x, float y) override { kinds_.push_back(0), put2(x, y); }
+	void line_to(float x, float y) override { kinds_.push_back(1), put2(x, y); }
+	void quad_to(float x1, float y1, float x, float y) override { kinds_.push_back(2), put2(x1, y1), put2(x, y); }
+	void curve_to(float x1, float y1, float x2, float y2, float x, float y) override { kinds_.push_back(3), put2(x1, y1), put2(x2, y2), put2(x, y); }
+	void close() override { kinds_.push_back(4); }
+
+private:
+	void put2(float a, float b)
+	{
+		coords_.push_back(a);
+		coords_.push_back(b);
+	}
+	std::vector<uint8_t> &kinds_;
+	std::vector<float> &coords_;
+};
+
 // The merged batch handed to the device, in the compact upload form (vgsdf_outlines_packed: one kind byte per
 // command plus the coordinates its kind carries).  All arrays live back to back in ONE page-locked block, in the
 // order vgsdf.h names for a single-copy upload: scale | shift_x | cmd_off | dat_off | (pad to 8) | coords | kinds.
@@ -287,6 +328,7 @@ public:
 	// Host half for the DEVICE front-end: cmap lookup, advance, scale / shift, and the raw
 	// outline commands (renderer.rs:104-116,130); everything else happens on the GPU.
 	static bool record(const Face &face, uint32_t index, OutlineBatch &batch);
+	static bool record(const Face &face, uint32_t index, PackedOutlineBatch &batch); // the same into the compact form
 	// Device front-end + raster for a recorded batch: fills rects (one per job) and `out` with
 	// the bitmaps of the glyphs that have a raster, packed in job order.  Hip mode only.
 	void render_outlines(const vgsdf_outlines &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,

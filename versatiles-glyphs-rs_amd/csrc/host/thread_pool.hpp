@@ -13,6 +13,7 @@
 //  * workers poll the word for ~100 us after a fork before they sleep on the condition variable (the next fork
 //    usually follows within microseconds), and the caller polls the count of finished items before it sleeps.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -108,18 +109,24 @@ private:
 			const uint32_t i = (uint32_t)(v & kMaxItems), total = (uint32_t)((v >> 24) & kMaxItems);
 			if (i >= total)
 				return;
-			if (!state_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire))
+			// a run of items per claim (1/8 of a worker's share): thousands of tiny items — a block file each, most of them
+			// empty — otherwise spend their time in failed compare-exchanges on this one word (5376 items on 32 threads:
+			// 0.45 ms of "encoding" that was contention)
+			const uint32_t take = std::min(total - i, std::max(1u, total / (n_ * 8u)));
+			if (!state_.compare_exchange_weak(v, v + take, std::memory_order_acq_rel, std::memory_order_acquire))
 				continue;
 			if (!failed_.load(std::memory_order_relaxed)) {
 				try {
-					(*fn_.load(std::memory_order_relaxed))(i, id);
+					const auto &fn = *fn_.load(std::memory_order_relaxed);
+					for (uint32_t k = i; k < i + take; k++)
+						fn(k, id);
 				} catch (const std::exception &e) {
 					std::lock_guard<std::mutex> l(err_mu_);
 					if (!failed_.exchange(true))
 						error_ = e.what();
 				}
 			}
-			if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == total) { // the last item: the caller may be asleep
+			if (done_.fetch_add(take, std::memory_order_acq_rel) + take == total) { // the last items: the caller may be asleep
 				{
 					std::lock_guard<std::mutex> l(done_mu_); // (pairs with the caller's wait: no lost wake-up)
 				}
