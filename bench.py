@@ -91,6 +91,15 @@ def pmc_entry(workload, variant):
         return None
 
 
+def cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max = "quota period"), or None without a quota"""
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
 def cpu_model():
     try:
         for ln in Path("/proc/cpuinfo").read_text().splitlines():
@@ -475,8 +484,11 @@ def main():
             "seconds": best[0],
             "single_thread": {"value": n_sample / secs1, "seconds": secs1},
             "cpu_model": cpu_model(),
+            "cpu_quota": cpu_quota(),
             "threads_note": f"threads = CPU affinity of this process ({len(os.sched_getaffinity(0))}), no cap "
-                            f"(VG_CPU_THREADS overrides); machine reports {os.cpu_count()} logical CPUs",
+                            f"(VG_CPU_THREADS overrides); machine reports {os.cpu_count()} logical CPUs; cpu_quota = CPUs the "
+                            "container's cgroup lets all of them use at once (null: no quota) — the GPU path's host pool runs "
+                            "under the same quota",
         }
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
 
