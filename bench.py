@@ -120,6 +120,40 @@ def steps_for(ctx, db, warmup, min_ms):
     return int(1.15 * min_ms / max(est, 1e-6)) + 1
 
 
+def in_library(n):
+    """fonts -> PBF bytes of Noto Sans all languages by ONE process on n device lanes (BASELINE.json configs[3] in the form a
+    host application links: SURVEY.md §8e), beside the same on one device"""
+    vg = load_product()
+    d4, p4 = workload_files("noto_all")
+    mm = vg.FontManager(True)
+    mm.add_font_with_name(d4, p4)
+    single = vg.Renderer.new_precise(0)
+    share = os.environ.get("VG_SHARE_GPU") == "1" or vg.device_count() < n
+    lanes = vg.Renderer.new_multi([0] * n if share else list(range(n)))
+
+    def best_of(renderer, k=8):
+        mm.render_glyphs(None, renderer)
+        best, tm = None, None
+        for _ in range(k):
+            t0 = time.perf_counter()
+            mm.render_glyphs(None, renderer)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, tm = dt, mm.timings()
+        return best, tm
+    b1, t1 = best_of(single)
+    bn, tn = best_of(lanes)
+    print(json.dumps({
+        "note": "fonts -> PBF bytes (PCIe inclusive, native NULL sink) of Noto Sans all languages by ONE process: "
+                "Renderer.new_multi deals the glyph shards to N device lanes (one host thread each), partial PBFs merge in "
+                "shared memory, counters reduced by vgsdf_reduce_counters (RCCL when the lanes sit on distinct devices)",
+        "devices": n, "lanes_share_one_device": share, "seconds": bn, "glyphs_per_s": tn["glyphs"] / bn,
+        "one_device_seconds": b1, "one_device_glyphs_per_s": t1["glyphs"] / b1, "reduced_counters": list(mm.reduced_counters()),
+        "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}), flush=True)
+    lanes.close()
+    single.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,7 +170,12 @@ def main():
                          "would distort the per-kernel durations)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of the other font workloads")
     ap.add_argument("--synthetic-outlines", type=int, default=0, help="outlines per rank for --workload synthetic")
+    ap.add_argument("--in-library", type=int, default=0, metavar="N",
+                    help="(run by rank 0 of an N > 1 run) ONE process renders Noto Sans all languages on N device lanes "
+                         "(vg_renderer_new_multi) and prints its own JSON object")
     args = ap.parse_args()
+    if args.in_library:
+        return in_library(args.in_library)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -307,37 +346,22 @@ def main():
         db5.free()
         del b5
     if world > 1 and not args.sharded and not synthetic and not args.no_configs:
-        # in-library form: ONE process (rank 0) drives all N devices through vg_renderer_new_multi while the other ranks
-        # wait (on the CPU: a gloo group, so that no collective kernel spins on their GPUs)
+        # in-library form: ONE process drives all N devices through vg_renderer_new_multi.  It runs as a CHILD of rank 0
+        # (this script with --in-library N: its own HIP / RCCL state, and a time limit — a collective that hangs there must
+        # not take the headline with it) while the other ranks wait on the CPU (a gloo group, so that no collective kernel
+        # spins on their GPUs).
         wait_group = dist.new_group(backend="gloo") if backend != "gloo" else None
         if rank == 0:
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                     "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             try:
-                d4, p4 = workload_files("noto_all")
-                mm = vg.FontManager(True)
-                mm.add_font_with_name(d4, p4)
-                single = vg.Renderer.new_precise(local_rank)
-                lanes = vg.Renderer.new_multi([0] * world if os.environ.get("VG_SHARE_GPU") == "1" else list(range(world)))
-
-                def best_of(renderer, n=8):
-                    mm.render_glyphs(None, renderer)
-                    best, tm = None, None
-                    for _ in range(n):
-                        t0 = time.perf_counter()
-                        mm.render_glyphs(None, renderer)
-                        dt = time.perf_counter() - t0
-                        if best is None or dt < best:
-                            best, tm = dt, mm.timings()
-                    return best, tm
-                b1, t1 = best_of(single)
-                bn, tn = best_of(lanes)
-                multi["in_library"] = {
-                    "note": "fonts -> PBF bytes (PCIe inclusive, native NULL sink) of Noto Sans all languages by ONE process: "
-                            "Renderer.new_multi(devices 0..N-1) deals the glyph shards to N device lanes (one host thread each), "
-                            "partial PBFs merge in shared memory, counters reduced by vgsdf_reduce_counters (RCCL)",
-                    "devices": world, "seconds": bn, "glyphs_per_s": tn["glyphs"] / bn, "one_device_seconds": b1,
-                    "one_device_glyphs_per_s": t1["glyphs"] / b1, "reduced_counters": list(mm.reduced_counters()),
-                    "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
-                lanes.close(); single.close()
+                cp = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--in-library", str(world)], env=env,
+                                    capture_output=True, text=True, timeout=150)
+                lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                multi["in_library"] = json.loads(lines[-1]) if lines else {"error": f"exit {cp.returncode}: {cp.stderr[-400:]}"}
+            except subprocess.TimeoutExpired:
+                multi["in_library"] = {"error": "no result within 150 s (child process killed)"}
             except Exception as e:  # noqa: BLE001  (the line must still be printed)
                 multi["in_library"] = {"error": f"{type(e).__name__}: {e}"}
         dist.barrier(group=wait_group) if wait_group is not None else dist.barrier()

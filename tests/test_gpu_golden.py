@@ -81,6 +81,26 @@ def test_synthetic_benchmark_batch_sha(vg, ctx):
     assert np.array_equal(quarter, out[:quarter.size])
 
 
+@pytest.mark.parametrize("rank", [1, 3, 7])
+def test_synthetic_ranges_of_the_other_ranks(vg, ctx, oracle, rank):
+    """config 5 hands rank r the outlines [8192 r, 8192 (r + 1)) of the 65 536 (BASELINE.json configs[4]); the fixtures hold
+    rank 0's range only (the ranges 8192..65535 were never rendered).  A window at the start, inside and at the
+    very end of another rank's range against the oracle, and the windows rendered alone against the same outlines rendered
+    inside a larger batch of that range."""
+    from versatiles_glyphs_rs_amd import synthetic as S
+    first = rank * 8192
+    big = ctx.render_batch(S.make_batch(first, 1024)).reshape(1024, S.H, S.W)
+    for off in (0, 500, 8192 - 48):
+        smp = S.make_batch(first + off, 48)
+        got = ctx.render_batch(smp)
+        ref, _ = oracle.sdf_render_batch(smp, oracle.PRECISE, oracle.default_threads())
+        assert np.array_equal(got, ref), (rank, off)
+        if off + 48 <= 1024:
+            assert np.array_equal(got.reshape(48, S.H, S.W), big[off:off + 48])
+    # the draws of consecutive ranks do not overlap: last outline of this range != first of the next
+    assert not np.array_equal(S.outlines(first + 8191, 1), S.outlines((first + 8192) % 65536, 1))
+
+
 def test_full_size_properties(vg, ctx):
     """Properties that need no reference, at the benchmark's full batch (Noto Sans Regular):
     the two kernel variants agree byte for byte; rendering is idempotent; glyph order inside a
