@@ -303,8 +303,7 @@ bool Renderer::record(const Face &face, uint32_t index, PackedOutlineBatch &batc
 	if (!glyph_id)
 		return false;
 	const double scale = (double)GLYPH_SIZE / (double)face.units_per_em(); // :107
-	PackedRecorder rec(batch.kinds, batch.coords);
-	face.outline_glyph(*glyph_id, rec); // :109-111, callbacks only
+	face.outline_glyph_packed(*glyph_id, batch.kinds, batch.coords); // :109-111, callbacks only
 	const double advance_float = (double)face.glyph_hor_advance(*glyph_id).value_or(0) * scale * 0.95; // :115
 	const uint32_t advance = to_u32(std::round(advance_float));                                          // :116
 	GlyphJob job;

@@ -195,26 +195,6 @@ struct PackedOutlineBatch {
 	}
 };
 
-// OutlineBuilder sink for it
-class PackedRecorder final : public OutlineBuilder {
-public:
-	PackedRecorder(std::vector<uint8_t> &kinds, std::vector<float> &coords) : kinds_(kinds), coords_(coords) {}
-	void move_to(float x, float y) override { kinds_.push_back(0), put2(x, y); }
-	void line_to(float x, float y) override { kinds_.push_back(1), put2(x, y); }
-	void quad_to(float x1, float y1, float x, float y) override { kinds_.push_back(2), put2(x1, y1), put2(x, y); }
-	void curve_to(float x1, float y1, float x2, float y2, float x, float y) override { kinds_.push_back(3), put2(x1, y1), put2(x2, y2), put2(x, y); }
-	void close() override { kinds_.push_back(4); }
-
-private:
-	void put2(float a, float b)
-	{
-		coords_.push_back(a);
-		coords_.push_back(b);
-	}
-	std::vector<uint8_t> &kinds_;
-	std::vector<float> &coords_;
-};
-
 // The merged batch handed to the device, in the compact upload form (vgsdf_outlines_packed: one kind byte per
 // command plus the coordinates its kind carries).  All arrays live back to back in ONE page-locked block, in the
 // order vgsdf.h names for a single-copy upload: scale | shift_x | cmd_off | dat_off | (pad to 8) | coords | kinds.

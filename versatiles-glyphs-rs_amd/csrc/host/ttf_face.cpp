@@ -420,10 +420,12 @@ struct Affine {
 	}
 };
 
-// Turns TrueType contour points into move/line/quad callbacks (ttf-parser glyf.rs Builder)
-class ContourEmitter {
+// Turns TrueType contour points into move/line/quad callbacks (ttf-parser glyf.rs Builder).  B: the sink — the
+// OutlineBuilder interface (virtual calls), or a concrete recorder whose calls inline (the recording path of the device
+// front-end spends as long in the sink as in the walk: 0.8 of 1.75 us per glyph).
+template <class B> class ContourEmitter {
 public:
-	ContourEmitter(OutlineBuilder &out, const Affine &t) : out_(out), t_(t), plain_(t.identity()) {}
+	ContourEmitter(B &out, const Affine &t) : out_(out), t_(t), plain_(t.identity()) {}
 
 	void point(float x, float y, bool on_curve, bool last_of_contour)
 	{
@@ -502,7 +504,7 @@ private:
 		out_.quad_to(c.x, c.y, p.x, p.y);
 	}
 
-	OutlineBuilder &out_;
+	B &out_;
 	Affine t_;
 	bool plain_;
 	std::optional<P> start_, lead_off_, pending_off_;
@@ -513,7 +515,7 @@ constexpr int kMaxComponentDepth = 32;
 enum : uint8_t { ON_CURVE = 0x01, X_SHORT = 0x02, Y_SHORT = 0x04, REPEAT = 0x08, X_SAME_POS = 0x10, Y_SAME_POS = 0x20 };
 
 // simple glyph body (after numberOfContours + bbox); false = malformed (ttf-parser -> None)
-bool walk_simple(Bytes body, uint16_t n_contours, ContourEmitter &em)
+template <class B> bool walk_simple(Bytes body, uint16_t n_contours, ContourEmitter<B> &em)
 {
 	if (!body.has(0, (size_t)n_contours * 2))
 		return false;
@@ -602,9 +604,9 @@ bool walk_simple(Bytes body, uint16_t n_contours, ContourEmitter &em)
 
 } // namespace
 
-struct GlyfWalker {
+template <class B> struct GlyfWalker {
 	const Face &face;
-	OutlineBuilder &out;
+	B &out;
 
 	bool walk(Bytes glyph, int depth, const Affine &t)
 	{
@@ -615,7 +617,7 @@ struct GlyfWalker {
 		if (n_contours > 0) {
 			if (glyph.size() < 10)
 				return false;
-			ContourEmitter em(out, t);
+			ContourEmitter<B> em(out, t);
 			return walk_simple(body, (uint16_t)n_contours, em);
 		}
 		if (n_contours == 0 || glyph.size() < 10)
@@ -681,7 +683,65 @@ bool Face::outline_glyph(uint16_t gid, OutlineBuilder &builder) const
 	const auto g = glyph_data(gid);
 	if (!g)
 		return false;
-	GlyfWalker w{*this, builder};
+	GlyfWalker<OutlineBuilder> w{*this, builder};
+	return w.walk(*g, 0, Affine{});
+}
+
+namespace {
+// the callbacks in the compact upload form of vgsdf_outlines_packed: a kind byte per command + the coordinates it carries
+struct PackedSink {
+	std::vector<uint8_t> &kinds;
+	std::vector<float> &coords;
+	void move_to(float x, float y)
+	{
+		kinds.push_back(0);
+		coords.push_back(x);
+		coords.push_back(y);
+	}
+	void line_to(float x, float y)
+	{
+		kinds.push_back(1);
+		coords.push_back(x);
+		coords.push_back(y);
+	}
+	void quad_to(float x1, float y1, float x, float y)
+	{
+		kinds.push_back(2);
+		coords.push_back(x1);
+		coords.push_back(y1);
+		coords.push_back(x);
+		coords.push_back(y);
+	}
+	void close() { kinds.push_back(4); }
+};
+// (CFF charstrings go through the OutlineBuilder interface)
+struct PackedSinkVirtual final : OutlineBuilder {
+	PackedSink s;
+	explicit PackedSinkVirtual(PackedSink p) : s(p) {}
+	void move_to(float x, float y) override { s.move_to(x, y); }
+	void line_to(float x, float y) override { s.line_to(x, y); }
+	void quad_to(float x1, float y1, float x, float y) override { s.quad_to(x1, y1, x, y); }
+	void curve_to(float x1, float y1, float x2, float y2, float x, float y) override
+	{
+		s.kinds.push_back(3);
+		for (float v : {x1, y1, x2, y2, x, y})
+			s.coords.push_back(v);
+	}
+	void close() override { s.close(); }
+};
+} // namespace
+
+bool Face::outline_glyph_packed(uint16_t gid, std::vector<uint8_t> &kinds, std::vector<float> &coords) const
+{
+	PackedSink sink{kinds, coords};
+	if (!has_glyf_outlines() && cff_) {
+		PackedSinkVirtual v(sink);
+		return cff_->outline(gid, v);
+	}
+	const auto g = glyph_data(gid);
+	if (!g)
+		return false;
+	GlyfWalker<PackedSink> w{*this, sink};
 	return w.walk(*g, 0, Affine{});
 }
 

@@ -68,6 +68,10 @@ public:
 	// Emits the glyph's outline; returns false when ttf-parser would return None
 	// (callbacks already delivered stay delivered, as in the crate).
 	bool outline_glyph(uint16_t glyph_id, OutlineBuilder &builder) const;
+	// The same callbacks appended to `kinds` / `coords` in the compact upload form of vgsdf_outlines_packed (kind byte
+	// 0..4 = move / line / quad / curve / close + the coordinates the kind carries); glyf outlines are walked with the sink
+	// inlined (no virtual call per point).
+	bool outline_glyph_packed(uint16_t glyph_id, std::vector<uint8_t> &kinds, std::vector<float> &coords) const;
 	// ttf-parser's `tables().cmap.is_some()`; the reference refuses fonts without one (metadata.rs:104-107)
 	bool has_cmap() const { return has_cmap_; }
 	// glyph outlines this reader can emit: `glyf` + `loca`, or `CFF ` charstrings (ttf-parser's order: glyf first).
@@ -101,7 +105,7 @@ private:
 	std::shared_ptr<const CffTable> cff_;
 	size_t loca_entries_ = 0;
 
-	friend struct GlyfWalker;
+	template <class B> friend struct GlyfWalker;
 };
 
 } // namespace vg
