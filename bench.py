@@ -193,6 +193,7 @@ def main():
     if os.environ.get("VG_SHARE_GPU") == "1":
         local_rank = 0
     coll_dev = "cuda" if backend == "nccl" else "cpu"
+    coll_fallback = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -212,6 +213,7 @@ def main():
                     dist.destroy_process_group()
                 except Exception:               # noqa: BLE001
                     pass
+                coll_fallback = f"RCCL failed ({type(e).__name__}: {str(e)[:200]}); barrier, max(time) and the counter sum went over gloo"
                 backend, coll_dev = "gloo", "cpu"
                 dist.init_process_group(backend="gloo", timeout=timedelta(seconds=300))
         else:
@@ -408,6 +410,7 @@ def main():
                             "owners afterwards)" if args.sharded else
                             f"replica x{world} (glyph batches shard with no exchange)"),
             "collectives": ("none" if world == 1 else f"{backend}: barrier, max(time), sum of 3 counters"),
+            "collectives_fallback": coll_fallback,  # not None: RCCL was asked for and did not come up (said loudly here)
             "timed_region_ms": elapsed * 1e3,
         },
         "mpixel_sdf_per_s": counters[2] * steps / elapsed * 1e-6,
