@@ -3,9 +3,9 @@
  *
  * Scalar f64 restatement of the reference's per-glyph SDF path.  Every function cites
  * the reference file:line it follows (paths relative to /root/reference/).  Compile
- * with -ffp-contract=off (Rust never fuses a*b+c).  The `CFF ` reader further down restates a
- * third-party crate's behaviour from Adobe's technical notes; no reference fixture pins it
- * (parity unpinned, see its header comment).
+ * with -ffp-contract=off (Rust never fuses a*b+c).  The `CFF ` / `CFF2` readers further down restate a
+ * third-party crate's behaviour from Adobe's technical notes and the OpenType specification; no
+ * reference fixture pins them (parity unpinned, see their header comments).
  */
 #define _POSIX_C_SOURCE 200809L
 #include "vg_oracle.h"
@@ -42,7 +42,7 @@ typedef struct {
 struct vgo_font {
 	uint8_t *data;
 	size_t len;
-	span head, maxp, hhea, hmtx, loca, glyf, cmap, cff;
+	span head, maxp, hhea, hmtx, loca, glyf, cmap, cff, cff2, fvar;
 	int units_per_em, num_glyphs, num_hmetrics, loca_long;
 	size_t loca_count;
 };
@@ -84,6 +84,8 @@ vgo_font *vgo_font_open(const uint8_t *data, size_t len)
 	f->glyf = find_table(f->data, len, "glyf");
 	f->cmap = find_table(f->data, len, "cmap");
 	f->cff = find_table(f->data, len, "CFF ");
+	f->cff2 = find_table(f->data, len, "CFF2");
+	f->fvar = find_table(f->data, len, "fvar");
 	if (!f->head.p || f->head.len < 54 || !f->maxp.p || f->maxp.len < 6 || !f->hhea.p ||
 	    f->hhea.len < 36) {
 		vgo_font_close(f);
@@ -782,22 +784,24 @@ static uint32_t cff_off(const cff_index *ix, uint32_t i)
 	return v;
 }
 
-/* parses the INDEX at `at`; returns the position behind it, 0 on malformed data */
-static size_t cff_index_at(span t, size_t at, cff_index *ix)
+/* parses the INDEX at `at` (count of `cw` = 2 bytes, or 4 in CFF2); returns the position behind it, 0 on malformed data */
+static size_t cff_index_wide(span t, size_t at, cff_index *ix, size_t cw)
 {
 	memset(ix, 0, sizeof *ix);
 	ix->tab = t;
-	if (!rd_ok(t.len, at, 2))
+	if (!rd_ok(t.len, at, cw))
 		return 0;
-	ix->count = be16(t.p + at);
-	if (ix->count == 0)
-		return at + 2;
-	if (!rd_ok(t.len, at, 3))
+	ix->count = cw == 4 ? be32(t.p + at) : be16(t.p + at);
+	if (ix->count == 0 || ix->count == 0xFFFFFFFFu) {
+		ix->count = 0;
+		return at + cw;
+	}
+	if (!rd_ok(t.len, at, cw + 1))
 		return 0;
-	ix->off_size = t.p[at + 2];
+	ix->off_size = t.p[at + cw];
 	if (ix->off_size < 1 || ix->off_size > 4)
 		return 0;
-	ix->offs = at + 3;
+	ix->offs = at + cw + 1;
 	size_t n_off = ((size_t)ix->count + 1) * ix->off_size;
 	if (!rd_ok(t.len, ix->offs, n_off))
 		return 0;
@@ -807,6 +811,8 @@ static size_t cff_index_at(span t, size_t at, cff_index *ix)
 		return 0;
 	return ix->base + last;
 }
+
+static size_t cff_index_at(span t, size_t at, cff_index *ix) { return cff_index_wide(t, at, ix, 2); }
 
 static int cff_get(const cff_index *ix, uint32_t i, span *out)
 {
@@ -827,14 +833,15 @@ typedef struct {
 } cff_operands;
 typedef void (*cff_dict_fn)(int op, const cff_operands *a, void *ctx);
 
-static int cff_dict(span d, cff_dict_fn fn, void *ctx)
+/* v2: the DICTs of a CFF2 table, where every byte that is not a number is an operator (22 vsindex, 23 blend, 24 vstore) */
+static int cff_dict_any(span d, cff_dict_fn fn, void *ctx, int v2)
 {
 	cff_operands a;
 	a.n = 0;
 	size_t p = 0;
 	while (p < d.len) {
 		uint8_t b = d.p[p];
-		if (b <= 21) {
+		if (b <= 21 || (v2 && (b <= 27 || b == 31 || b == 255))) {
 			int op = b;
 			p++;
 			if (b == 12) {
@@ -888,6 +895,8 @@ static int cff_dict(span d, cff_dict_fn fn, void *ctx)
 	return 1;
 }
 
+static int cff_dict(span d, cff_dict_fn fn, void *ctx) { return cff_dict_any(d, fn, ctx, 0); }
+
 typedef struct {
 	span tab;
 	cff_index gsubrs, chars, fd_array;
@@ -897,6 +906,12 @@ typedef struct {
 	size_t priv_size, priv_at;
 	int have_priv, bad;
 	size_t chars_at, fd_array_at;
+	/* CFF2 */
+	int v2, have_fd_array, have_vstore, n_coords;
+	size_t vstore_at;
+	span store;              /* the ItemVariationStore (behind its u16 length) */
+	size_t regions_at;       /* of the VariationRegionList inside `store` */
+	uint32_t n_axes, n_region_records, n_data;
 } cff_font;
 
 static void cff_top_op(int op, const cff_operands *a, void *vctx)
@@ -969,6 +984,157 @@ static int cff_open(span t, cff_font *c)
 	} else if (c->have_priv) {
 		c->have_lsubrs = cff_local_subrs(t, c->priv_at, c->priv_size, &c->lsubrs);
 	}
+	return 1;
+}
+
+/* ------------------------------------------------------------------------------------
+ * `CFF2` — the crate's cff2 table (used when the face has neither glyf nor a readable `CFF `), at the variation
+ * coordinates the reference leaves untouched: zero on every fvar axis, NO coordinates without fvar.
+ * Restated from the OpenType specification (CFF2, ItemVariationStore) and the crate's observable rules
+ * (see the product's csrc/host/cff.hpp for the list).  PARITY UNPINNED: no fixture; tests compare this reader,
+ * the product's and fontTools at the default position.
+ * ---------------------------------------------------------------------------------- */
+static void cff2_top_op(int op, const cff_operands *a, void *vctx)
+{
+	cff_font *c = (cff_font *)vctx;
+	int one = a->n == 1 && a->v[0] >= 0 && a->v[0] <= 4294967295.0;
+	if (op == 17) {
+		if (one)
+			c->chars_at = (size_t)a->v[0];
+		else
+			c->bad = 1;
+	} else if (op == 1236) {
+		c->have_fd_array = one;
+		c->fd_array_at = one ? (size_t)a->v[0] : 0;
+	} else if (op == 24) {
+		c->have_vstore = one;
+		c->vstore_at = one ? (size_t)a->v[0] : 0;
+	}
+}
+
+typedef struct {
+	size_t a, b;
+	int n_ops, done;
+	int want_op, want_n;
+} cff2_first_ctx;
+
+/* remembers the operands of the FIRST occurrence of operator want_op (whether or not their number fits) */
+static void cff2_first_op(int op, const cff_operands *a, void *vctx)
+{
+	cff2_first_ctx *f = (cff2_first_ctx *)vctx;
+	if (f->done || op != f->want_op)
+		return;
+	f->done = 1;
+	f->n_ops = 0;
+	if (a->n != f->want_n)
+		return;
+	for (int i = 0; i < a->n; i++)
+		if (!(a->v[i] >= 0 && a->v[i] <= 4294967295.0))
+			return;
+	f->a = (size_t)a->v[0];
+	f->b = a->n > 1 ? (size_t)a->v[1] : 0;
+	f->n_ops = a->n;
+}
+
+static int cff2_open(span t, int n_coords, cff_font *c)
+{
+	memset(c, 0, sizeof *c);
+	c->tab = t;
+	c->v2 = 1;
+	c->n_coords = n_coords;
+	if (t.len < 5 || t.p[0] != 2)
+		return 0;
+	size_t top_at = t.p[2] > 5 ? t.p[2] : 5, top_len = be16(t.p + 3);
+	if (!rd_ok(t.len, top_at, top_len))
+		return 0;
+	span top = {t.p + top_at, top_len};
+	(void)cff_dict_any(top, cff2_top_op, c, 1);
+	if (c->bad || !c->chars_at)
+		return 0;
+	if (!cff_index_wide(t, top_at + top_len, &c->gsubrs, 4) || !cff_index_wide(t, c->chars_at, &c->chars, 4))
+		return 0;
+	if (c->have_vstore) {
+		if (!rd_ok(t.len, c->vstore_at, 2))
+			return 0;
+		c->store.p = t.p + c->vstore_at + 2;
+		c->store.len = t.len - c->vstore_at - 2;
+		if (c->store.len < 8 || be16(c->store.p) != 1)
+			return 0;
+		c->regions_at = be32(c->store.p + 2);
+		c->n_data = be16(c->store.p + 6);
+		if (!rd_ok(c->store.len, 8, (size_t)c->n_data * 4) || !rd_ok(c->store.len, c->regions_at, 4))
+			return 0;
+		c->n_axes = be16(c->store.p + c->regions_at);
+		c->n_region_records = c->n_axes * (uint32_t)be16(c->store.p + c->regions_at + 2);
+		if (c->n_region_records > 0xFFFF || !rd_ok(c->store.len, c->regions_at + 4, (size_t)c->n_region_records * 6))
+			return 0;
+	}
+	if (c->have_fd_array) {
+		if (!cff_index_wide(t, c->fd_array_at, &c->fd_array, 4))
+			return 0;
+		for (uint32_t i = 0; i < c->fd_array.count; i++) {
+			span fd;
+			if (!cff_get(&c->fd_array, i, &fd))
+				continue;
+			cff2_first_ctx pv = {0, 0, 0, 0, 18, 2};
+			(void)cff_dict_any(fd, cff2_first_op, &pv, 1);
+			if (pv.n_ops != 2)
+				continue;
+			if (!rd_ok(t.len, pv.b, pv.a)) /* Private DICT (size, offset) outside the table: no table */
+				return 0;
+			span priv = {t.p + pv.b, pv.a};
+			cff2_first_ctx sb = {0, 0, 0, 0, 19, 1};
+			(void)cff_dict_any(priv, cff2_first_op, &sb, 1);
+			if (sb.n_ops != 1)
+				continue;
+			if (!cff_index_wide(t, pv.b + sb.a, &c->lsubrs, 4))
+				return 0;
+			c->have_lsubrs = 1;
+			break;
+		}
+	}
+	return 1;
+}
+
+/* factors of the regions of ItemVariationData `index` at the default position -> out[0 .. *n); 0: no such subtable,
+ * or more regions than the crate keeps (64) */
+static int cff2_scalars(const cff_font *c, uint32_t index, float *out, int *n)
+{
+	if (!c->have_vstore || index >= c->n_data)
+		return 0;
+	const span st = c->store;
+	size_t at = be32(st.p + 8 + (size_t)index * 4);
+	if (at > st.len || !rd_ok(st.len, at + 4, 2))
+		return 0;
+	uint32_t cnt = be16(st.p + at + 4);
+	if (cnt > 64 || !rd_ok(st.len, at + 6, (size_t)cnt * 2))
+		return 0;
+	for (uint32_t k = 0; k < cnt; k++) {
+		uint32_t region = be16(st.p + at + 6 + (size_t)k * 2);
+		float v = 1.0f;
+		for (int i = 0; i < c->n_coords && v != 0.0f; i++) {
+			uint32_t base = region * c->n_axes, rec = base + (uint32_t)i; /* 16-bit arithmetic in the crate: overflow = no record */
+			if (base > 0xFFFF || rec > 0xFFFF || rec >= c->n_region_records) {
+				v = 0.0f;
+				break;
+			}
+			const uint8_t *q = st.p + c->regions_at + 4 + (size_t)rec * 6;
+			int start = (int16_t)be16(q), peak = (int16_t)be16(q + 2), end = (int16_t)be16(q + 4);
+			/* evaluate_axis at coordinate 0 */
+			float f;
+			if (start > peak || peak > end)
+				f = 1.0f;
+			else if (start < 0 && end > 0 && peak != 0)
+				f = 1.0f;
+			else if (peak == 0)
+				f = 1.0f;
+			else
+				f = 0.0f; /* 0 <= start or end <= 0 */
+			v = f == 0.0f ? 0.0f : v * f;
+		}
+		out[k] = v;
+	}
+	*n = (int)cnt;
 	return 1;
 }
 
@@ -1073,10 +1239,12 @@ typedef struct {
 	cmd_sink *sink;
 	cff_index lsubrs;
 	int have_lsubrs;
-	float st[48];
+	float st[513];
 	int sp;
 	float x, y;
 	int moved, path_open, width_seen, ended;
+	int had_vsindex, had_blend, n_scal; /* CFF2 */
+	float scal[64];
 	uint32_t stems;
 	float bx0, by0, bx1, by1;
 	int any_point;
@@ -1202,7 +1370,7 @@ static int cff_exec(cff_run *r, span cs, int depth)
 				v = (float)(int32_t)be32(cs.p + p) / 65536.0f;
 				p += 4;
 			}
-			if (r->sp >= 48)
+			if (r->sp >= (r->font->v2 ? 513 : 48))
 				return 0;
 			r->st[r->sp++] = v;
 			continue;
@@ -1226,8 +1394,11 @@ static int cff_exec(cff_run *r, span cs, int depth)
 			}
 			r->stems += (uint32_t)n >> 1;
 			p += (r->stems + 7) >> 3;
-			if (p > cs.len)
-				return 0;
+			if (p > cs.len) {
+				if (!r->font->v2)
+					return 0;
+				p = cs.len;
+			}
 			break;
 		case 21: { /* rmoveto */
 			int skip = n == 3 && !r->width_seen; /* the width operand exists once per charstring */
@@ -1383,9 +1554,37 @@ static int cff_exec(cff_run *r, span cs, int depth)
 				return p == cs.len;
 			break;
 		}
+		case 15: { /* vsindex (CFF2) */
+			if (!r->font->v2 || r->had_blend || r->had_vsindex || n != 1)
+				return 0;
+			if (!(s[0] >= 0.0f && s[0] <= 65535.0f) || !cff2_scalars(r->font, (uint32_t)s[0], r->scal, &r->n_scal))
+				return 0;
+			r->had_vsindex = 1;
+			r->sp = 0;
+			break;
+		}
+		case 16: { /* blend (CFF2): value_0..value_{m-1}, k deltas for each value, m */
+			if (!r->font->v2 || n == 0)
+				return 0;
+			r->had_blend = 1;
+			float fm = s[--r->sp];
+			if (!(fm >= 0.0f && fm <= 65535.0f))
+				return 0;
+			size_t m = (size_t)fm, k = (size_t)r->n_scal, need = m * (k + 1);
+			if ((size_t)r->sp < need)
+				return 0;
+			float *val = s + ((size_t)r->sp - need), *del = val + m;
+			for (size_t i = m; i-- > 0;)       /* the crate pops: last value first, */
+				for (size_t j = k; j-- > 0;)   /* last region first */
+					val[i] += del[i * k + j] * r->scal[j];
+			r->sp -= (int)(m * k);
+			break;
+		}
 		case 11: /* return */
-			return 1;
+			return r->font->v2 ? 0 : 1;
 		case 14: /* endchar */
+			if (r->font->v2)
+				return 0;
 			if (n == 4 || (!r->width_seen && n == 5)) { /* seac: base glyph, then the accent at (adx, ady) */
 				const float *a = s + (n - 4);
 				r->width_seen = 1;
@@ -1473,12 +1672,44 @@ static void cff_outline(const vgo_font *f, int gid, cmd_sink *sink)
 	(void)cff_exec(&r, cs, 0);
 }
 
+static void cff2_outline(const vgo_font *f, int gid, cmd_sink *sink)
+{
+	/* coordinates of the face: one per fvar axis (<= 64) when fvar reads (version 1.0, axes > 0, records inside) */
+	int n_coords = 0;
+	if (f->fvar.p && f->fvar.len >= 10 && be32(f->fvar.p) == 0x00010000u) {
+		size_t at = be16(f->fvar.p + 4), n = be16(f->fvar.p + 8);
+		if (n && rd_ok(f->fvar.len, at, n * 20))
+			n_coords = n > 64 ? 64 : (int)n;
+	}
+	cff_font c;
+	span cs;
+	if (!cff2_open(f->cff2, n_coords, &c) || gid < 0 || !cff_get(&c.chars, (uint32_t)gid, &cs))
+		return;
+	cff_run r;
+	memset(&r, 0, sizeof r);
+	r.font = &c;
+	r.sink = sink;
+	r.lsubrs = c.lsubrs;
+	r.have_lsubrs = 1; /* (an empty INDEX when the font has none: the call fails on the index) */
+	r.width_seen = 1;  /* no width operand in CFF2 */
+	if (!cff2_scalars(&c, 0, r.scal, &r.n_scal))
+		return; /* the scalars of subtable 0 are loaded first: no store, no outline */
+	(void)cff_exec(&r, cs, 0);
+}
+
 int vgo_font_outline(const vgo_font *f, int gid, vgo_cmd *out, int cap)
 {
 	cmd_sink sink = {out, cap, 0};
 	span g;
-	if (!(f->glyf.p && f->loca.p) && f->cff.p) { /* ttf-parser: glyf first, then cff */
-		cff_outline(f, gid, &sink);
+	if (!(f->glyf.p && f->loca.p) && f->cff.p) { /* ttf-parser: glyf first, then cff, then cff2 */
+		cff_font probe;
+		if (cff_open(f->cff, &probe) || !f->cff2.p) {
+			cff_outline(f, gid, &sink);
+			return sink.n;
+		}
+	}
+	if (!(f->glyf.p && f->loca.p) && f->cff2.p) {
+		cff2_outline(f, gid, &sink);
 		return sink.n;
 	}
 	if (!glyph_data(f, gid, &g))

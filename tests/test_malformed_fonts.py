@@ -95,7 +95,7 @@ def _retag(data: bytes, old: bytes, new: bytes) -> bytes:
 
 def test_cff_and_cmapless_fonts_are_refused(vg):
     """A font whose outlines live in a table this reader cannot walk (here: a `CFF ` table that does not parse;
-    `CFF2` in tests/test_cff_outlines.py) must not silently render as empty glyphs, and a font without a cmap
+    a version-1 table under the `CFF2` tag in tests/test_cff_outlines.py) must not silently render as empty glyphs, and a font without a cmap
     table fails as in the reference ("Font has no cmap table", src/font/metadata.rs:104-107)."""
     from conftest import FIRA
     data = Path(FIRA).read_bytes()

@@ -8,13 +8,16 @@ namespace vg {
 
 namespace {
 
-constexpr int kMaxOperands = 48; // ttf-parser: MAX_ARGUMENTS_STACK_LEN
+constexpr int kMaxOperands = 48;   // ttf-parser: MAX_ARGUMENTS_STACK_LEN of cff1
+constexpr int kMaxOperands2 = 513; // ... of cff2
+constexpr size_t kMaxRegions = 64; // ttf-parser: scalars of one ItemVariationData (cff2)
 constexpr int kMaxDepth = 10;    // ttf-parser: STACK_LIMIT (nested subroutine calls)
 
 // DICT data (Technical Note #5176, section 4): operands followed by an operator
 struct DictReader {
-	explicit DictReader(Bytes dict) : d(dict) {}
+	explicit DictReader(Bytes dict, bool cff2_dict = false) : d(dict), cff2(cff2_dict) {}
 	Bytes d;
+	bool cff2; // CFF2 DICTs: 22 (vsindex), 23 (blend), 24 (vstore) are operators; so is every other non-number byte
 	size_t pos = 0;
 	std::vector<double> operands;
 	// next operator (two-byte operators as 1200 + second byte), -1 at the end, -2 on malformed data
@@ -23,7 +26,7 @@ struct DictReader {
 		operands.clear();
 		while (pos < d.size()) {
 			const uint8_t b = d.u8(pos);
-			if (b <= 21) {
+			if (b <= 21 || (cff2 && (b <= 27 || b == 31 || b == 255))) {
 				pos++;
 				if (b != 12)
 					return b;
@@ -84,22 +87,23 @@ bool to_offset(double v, size_t &out)
 
 } // namespace
 
-bool CffTable::parse_index(Bytes table, size_t at, Index &out, size_t &end)
+bool CffTable::parse_index(Bytes table, size_t at, Index &out, size_t &end, bool count32)
 {
 	out = Index{};
-	if (!table.has(at, 2))
+	const size_t cw = count32 ? 4 : 2; // CFF2: card32 counts
+	if (!table.has(at, cw))
 		return false;
-	const uint32_t count = table.u16(at);
-	if (count == 0) {
-		end = at + 2;
+	const uint32_t count = count32 ? table.u32(at) : table.u16(at);
+	if (count == 0 || count == 0xFFFFFFFFu) {
+		end = at + cw;
 		return true;
 	}
-	if (!table.has(at, 3))
+	if (!table.has(at, cw + 1))
 		return false;
-	const uint8_t off_size = table.u8(at + 2);
+	const uint8_t off_size = table.u8(at + cw);
 	if (off_size < 1 || off_size > 4)
 		return false;
-	const size_t offsets_at = at + 3, offsets_len = ((size_t)count + 1) * off_size;
+	const size_t offsets_at = at + cw + 1, offsets_len = ((size_t)count + 1) * off_size;
 	if (!table.has(offsets_at, offsets_len))
 		return false;
 	auto off = [&](uint32_t i) {
@@ -233,6 +237,144 @@ std::optional<CffTable> CffTable::parse(Bytes table)
 	return t;
 }
 
+namespace {
+
+// factor of one axis of a variation region at normalised coordinate 0 (the crate's evaluate_axis with coord = 0; all
+// values F2Dot14 as integers).  Only 0 and 1 can come out: the interpolating branches need start < 0 < end with the
+// peak off 0, which the second rule has already answered with 1.
+float axis_factor_at_default(int start, int peak, int end)
+{
+	if (start > peak || peak > end)
+		return 1.0f;
+	if (start < 0 && end > 0 && peak != 0)
+		return 1.0f;
+	if (peak == 0)
+		return 1.0f;
+	return 0.0f; // 0 <= start or end <= 0: outside the region (or on its border)
+}
+
+} // namespace
+
+// OpenType `CFF2` table, as the crate's cff2::Table::parse reads it: header, Top DICT (CharStrings 17, FDArray 12 36,
+// vstore 24), global subroutines behind the Top DICT, ItemVariationStore, the first local subroutines found.
+std::optional<CffTable> CffTable::parse2(Bytes table, uint32_t n_coords)
+{
+	if (!table.has(0, 5) || table.u8(0) != 2)
+		return std::nullopt;
+	CffTable t;
+	t.table_ = table;
+	t.cff2_ = true;
+	const size_t header_size = table.u8(2), top_len = table.u16(3);
+	const size_t top_at = header_size > 5 ? header_size : 5;
+	if (!table.has(top_at, top_len))
+		return std::nullopt;
+	size_t charstrings_at = 0, fd_array_at = 0, vstore_at = 0;
+	bool have_fd_array = false, have_vstore = false;
+	{
+		DictReader r(table.sub(top_at, top_len), true);
+		for (int op = r.next(); op != -1; op = r.next()) {
+			if (op == -2)
+				break; // (the crate stops at a number it cannot read and keeps what it has)
+			const auto &v = r.operands;
+			if (op == 17) {
+				if (v.size() != 1 || !to_offset(v[0], charstrings_at))
+					return std::nullopt;
+			} else if (op == 1236) {
+				have_fd_array = v.size() == 1 && to_offset(v[0], fd_array_at);
+			} else if (op == 24) {
+				have_vstore = v.size() == 1 && to_offset(v[0], vstore_at);
+			}
+		}
+	}
+	if (charstrings_at == 0)
+		return std::nullopt;
+	size_t end;
+	if (!parse_index(table, top_at + top_len, t.global_subrs_, end, true) || !parse_index(table, charstrings_at, t.charstrings_, end, true))
+		return std::nullopt;
+	if (have_vstore) {
+		// u16 length, then the ItemVariationStore: format (1), offset of the region list, offsets of the
+		// ItemVariationData subtables — all relative to the store
+		if (!table.has(vstore_at, 2))
+			return std::nullopt;
+		const Bytes st = table.from(vstore_at + 2);
+		if (!st.has(0, 8) || st.u16(0) != 1)
+			return std::nullopt;
+		const size_t regions_at = st.u32(2);
+		const uint32_t n_data = st.u16(6);
+		if (!st.has(8, (size_t)n_data * 4) || !st.has(regions_at, 4))
+			return std::nullopt;
+		const uint32_t axis_count = st.u16(regions_at), region_count = st.u16(regions_at + 2);
+		const uint32_t n_records = axis_count * region_count;
+		if (n_records > 0xFFFFu || !st.has(regions_at + 4, (size_t)n_records * 6))
+			return std::nullopt;
+		auto region_factor = [&](uint32_t region) {
+			float v = 1.0f;
+			for (uint32_t i = 0; i < n_coords; i++) {
+				// (flat record index in 16 bits, as the crate computes it: a face with more coordinates than the
+				// store has axes reads on into the next region's records)
+				const uint32_t rec = region * axis_count + i;
+				if (region * axis_count > 0xFFFFu || rec > 0xFFFFu || rec >= n_records)
+					return 0.0f;
+				const size_t at = regions_at + 4 + (size_t)rec * 6;
+				const float f = axis_factor_at_default(st.i16(at), st.i16(at + 2), st.i16(at + 4));
+				if (f == 0.0f)
+					return 0.0f;
+				v *= f;
+			}
+			return v;
+		};
+		t.blend_sets_.resize(n_data);
+		for (uint32_t d = 0; d < n_data; d++) {
+			const size_t at = st.u32(8 + (size_t)d * 4);
+			if (at > st.size() || !st.has(at + 4, 2))
+				continue; // not ok: a charstring that selects it ends there
+			const uint32_t n = st.u16(at + 4);
+			if (!st.has(at + 6, (size_t)n * 2) || n > kMaxRegions)
+				continue;
+			BlendSet &set = t.blend_sets_[d];
+			set.ok = true;
+			for (uint32_t k = 0; k < n; k++)
+				set.scalars.push_back(region_factor(st.u16(at + 6 + (size_t)k * 2)));
+		}
+	}
+	if (have_fd_array) {
+		Index fd_array;
+		if (!parse_index(table, fd_array_at, fd_array, end, true))
+			return std::nullopt;
+		for (uint32_t i = 0; i < fd_array.count; i++) {
+			const auto fd = fd_array.get(i);
+			if (!fd)
+				continue; // (the crate's iterator would stop here; an INDEX that parsed has no such entry)
+			size_t priv_size = 0, priv_at = 0;
+			bool have_priv = false;
+			DictReader fr(*fd, true);
+			for (int op = fr.next(); op != -1 && op != -2; op = fr.next())
+				if (op == 18) {
+					have_priv = fr.operands.size() == 2 && to_offset(fr.operands[0], priv_size) && to_offset(fr.operands[1], priv_at);
+					break;
+				}
+			if (!have_priv)
+				continue;
+			if (!table.has(priv_at, priv_size))
+				return std::nullopt;
+			size_t subrs_rel = 0;
+			bool have_subrs = false;
+			DictReader pr(table.sub(priv_at, priv_size), true);
+			for (int op = pr.next(); op != -1 && op != -2; op = pr.next())
+				if (op == 19) {
+					have_subrs = pr.operands.size() == 1 && to_offset(pr.operands[0], subrs_rel);
+					break;
+				}
+			if (!have_subrs)
+				continue;
+			if (!parse_index(table, priv_at + subrs_rel, t.private_.local_subrs, end, true))
+				return std::nullopt;
+			break; // the first Font DICT with local subroutines serves every glyph
+		}
+	}
+	return t;
+}
+
 const CffTable::Index *CffTable::local_subrs_for(uint16_t gid) const
 {
 	if (!cid_)
@@ -332,16 +474,32 @@ struct CffBounds {
 
 // One glyph's charstring program (Technical Note #5177).
 struct CharStringRun {
-	CharStringRun(const CffTable &table, OutlineBuilder &builder, CffBounds &bounds) : t(table), out(builder), bb(bounds) {}
+	CharStringRun(const CffTable &table, OutlineBuilder &builder, CffBounds &bounds)
+	    : t(table), out(builder), bb(bounds), cff2(table.cff2_), cap(table.cff2_ ? kMaxOperands2 : kMaxOperands), have_width(table.cff2_)
+	{
+	}
 	const CffTable &t;
 	OutlineBuilder &out;
 	CffBounds &bb;
+	const bool cff2;
+	const int cap; // operand stack limit of the table's version
 	const CffTable::Index *local = nullptr;
-	float stack[kMaxOperands];
+	float stack[kMaxOperands2];
 	int sp = 0;
 	float x = 0.0f, y = 0.0f;
-	bool has_move_to = false, first_move_to = true, have_width = false, has_endchar = false;
+	// (CFF2 charstrings carry no width: "already seen" makes every operand count exact)
+	bool has_move_to = false, first_move_to = true, have_width, has_endchar = false;
 	uint32_t stems = 0;
+	// CFF2: factors of the regions of the selected ItemVariationData, `vsindex` / `blend` bookkeeping
+	const std::vector<float> *scalars = nullptr;
+	bool had_vsindex = false, had_blend = false;
+	bool select_blend_set(uint32_t index)
+	{
+		if (index >= t.blend_sets_.size() || !t.blend_sets_[index].ok)
+			return false;
+		scalars = &t.blend_sets_[index].scalars;
+		return true;
+	}
 	void extend(float px, float py)
 	{
 		bb.x0 = px < bb.x0 ? px : bb.x0;
@@ -368,7 +526,7 @@ struct CharStringRun {
 	}
 	bool push(float v)
 	{
-		if (sp >= kMaxOperands)
+		if (sp >= cap)
 			return false;
 		stack[sp++] = v;
 		return true;
@@ -509,8 +667,11 @@ struct CharStringRun {
 				}
 				stems += (uint32_t)len >> 1; // an implied vstem
 				pos += (stems + 7) >> 3;
-				if (pos > cs.size())
-					return false;
+				if (pos > cs.size()) {
+					if (!cff2)
+						return false;
+					pos = cs.size(); // (cff2: the stream simply ends; there is no endchar to miss)
+				}
 				break;
 			}
 			case 21: // rmoveto
@@ -670,9 +831,45 @@ struct CharStringRun {
 				}
 				break;
 			}
+			case 15: // vsindex (CFF2): |- ivs vsindex |- , once and before the first blend
+			{
+				if (!cff2 || had_blend || had_vsindex || sp != 1)
+					return false;
+				const float v = stack[0];
+				if (!(v >= 0.0f && v <= 65535.0f) || !select_blend_set((uint32_t)v))
+					return false;
+				had_vsindex = true;
+				sp = 0;
+				break;
+			}
+			case 16: // blend (CFF2): n values, then their k deltas each, then n; the values stay, moved to the default position's sum
+			{
+				if (!cff2 || sp == 0)
+					return false;
+				had_blend = true;
+				const float fn = stack[--sp];
+				if (!(fn >= 0.0f && fn <= 65535.0f))
+					return false;
+				const size_t n = (size_t)fn, k = scalars->size();
+				const size_t len = n * (k + 1);
+				if ((size_t)sp < len)
+					return false;
+				const size_t start = (size_t)sp - len;
+				// popped from the top: value n - 1 first, each with its last region's delta first (f32, one product and one sum each)
+				for (size_t i = n; i-- > 0;)
+					for (size_t j = 0; j < k; j++) {
+						const float delta = stack[--sp];
+						stack[start + i] += delta * (*scalars)[k - j - 1];
+					}
+				break;
+			}
 			case 11: // return
+				if (cff2)
+					return false; // (not an operator of CFF2: a subroutine ends with its data)
 				return true;
 			case 14: // endchar
+				if (cff2)
+					return false;
 				if (sp == 4 || (!have_width && sp == 5)) {
 					// seac form: adx ady bchar achar — the base glyph, then the accent moved by (adx, ady), each a
 					// charstring of its own (path, hints and width operand start afresh)
@@ -781,7 +978,7 @@ struct CharStringRun {
 				break;
 			}
 			default:
-				return false; // 0, 2, 9, 13, 15, 16, 17: reserved
+				return false; // 0, 2, 9, 13, 17 (and 15, 16 outside CFF2): reserved
 			}
 		}
 		return true;
@@ -796,8 +993,15 @@ bool CffTable::outline(uint16_t gid, OutlineBuilder &builder) const
 	CffBounds bb;
 	CharStringRun r(*this, builder, bb);
 	r.local = local_subrs_for(gid);
-	if (!r.run(*cs, 0) || !r.has_endchar)
+	if (cff2_) {
+		// the scalars of ItemVariationData 0 are loaded before the first operator: no store, no outline
+		if (!r.select_blend_set(0) || !r.run(*cs, 0))
+			return false;
+		// (no endchar in CFF2 and no close() for the last contour: RingBuilder::into_rings saves the open ring,
+		// /root/reference/src/render/ring_builder.rs:26-29)
+	} else if (!r.run(*cs, 0) || !r.has_endchar) {
 		return false;
+	}
 	// ttf-parser: a glyph that produced no point has no outline (ZeroBBox); neither has one whose bbox leaves i16
 	if (bb.x0 == std::numeric_limits<float>::max())
 		return false;

@@ -83,12 +83,13 @@ std::unique_ptr<FontFileEntry> FontFileEntry::create(std::vector<uint8_t> data, 
 			*err = "Font has no cmap table";
 		return nullptr;
 	}
-	// The reference renders `glyf`, `CFF ` and `CFF2` outlines through ttf-parser; this reader walks the first two.
-	// Refuse a font whose outlines it cannot walk loudly instead of writing PBFs whose glyphs are all empty.  (A
-	// font with no outline table at all renders empty glyphs in the reference too: outline_glyph -> None.)
+	// The reference renders `glyf`, `CFF ` and `CFF2` outlines through ttf-parser, and so does this reader.  A font
+	// whose only outline table it cannot open (a malformed `CFF ` / `CFF2`: the crate drops such a table and renders
+	// empty glyphs) is refused loudly instead of writing PBFs whose glyphs are all empty.  (A font with no outline
+	// table at all renders empty glyphs in the reference too: outline_glyph -> None.)
 	if (e->face_.has_unsupported_outlines()) {
 		if (err)
-			*err = "CFF2 outlines (or an unreadable CFF table) are not supported: glyf and CFF version 1 fonts only";
+			*err = "the font's CFF / CFF2 table cannot be read and it has no glyf outlines";
 		return nullptr;
 	}
 	e->codepoints_ = e->face_.unicode_codepoints();

@@ -61,8 +61,22 @@ std::optional<Face> Face::parse(const uint8_t *data, size_t len)
 		else
 			f.cff_unreadable_ = true;
 	}
-	if (!f.cff_ && !find_table(file, "CFF2").empty())
-		f.cff_unreadable_ = true;
+	if (const Bytes cff2 = find_table(file, "CFF2"); !f.cff_ && !cff2.empty()) {
+		// ttf-parser: glyf, then cff1, then cff2 — drawn at the face's variation coordinates, which the reference
+		// leaves at their defaults: one (zero) coordinate per `fvar` axis, at most 64, none without a readable `fvar`
+		// (version 1.0, at least one axis, the axis records of 20 bytes each inside the table)
+		uint32_t n_coords = 0;
+		if (const Bytes fvar = find_table(file, "fvar"); fvar.has(0, 10) && fvar.u32(0) == 0x00010000u) {
+			const size_t axes_at = fvar.u16(4);
+			const uint32_t n_axes = fvar.u16(8);
+			if (n_axes != 0 && fvar.has(axes_at, (size_t)n_axes * 20))
+				n_coords = std::min<uint32_t>(n_axes, 64);
+		}
+		if (auto t = CffTable::parse2(cff2, n_coords))
+			f.cff_ = std::make_shared<const CffTable>(std::move(*t));
+		else
+			f.cff_unreadable_ = true;
+	}
 	const Bytes cmap = find_table(file, "cmap");
 	f.has_cmap_ = cmap.has(0, 4);
 	if (cmap.has(0, 4)) {
