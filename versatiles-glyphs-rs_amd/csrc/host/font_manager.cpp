@@ -326,15 +326,20 @@ unsigned FontManager::worker_count() const
 		return 1;
 	if (threads_)
 		return threads_;
-	// VG_THREADS or set_threads() override.  Default: twice the CPUs the process may use (measured on a 16-CPU quota:
-	// 8 / 16 / 24 / 32 / 48 / 64 threads give 4.3 / 5.4 / 5.7 / 5.9 / 5.3 / 4.9 M glyphs/s end to end on Noto Sans — the
-	// phases are a few hundred microseconds long and a second thread per CPU hides the wake-up of the first), at most 64:
-	// beyond that the fork / join of a phase costs more than the phase.  (Rounds 1-2 capped the pool at 16.)
+	// VG_THREADS or set_threads() override.  Default: 1.5 x the CPUs the process may use, at most 64 (beyond that the
+	// fork / join of a phase costs more than the phase; rounds 1-2 capped the pool at 16).  The phases are a few hundred
+	// microseconds long and some threads beyond one per CPU hide the wake-up of the others — but a container's CPU quota
+	// counts CPU TIME per 100 ms period, spinning included, and a run longer than one period is throttled when pool +
+	// spinners exceed it (tools/sustained_e2e.py on a 16-CPU quota, 2 s runs, glyphs/s of the 21 fixture fonts / of Noto
+	// Sans Regular alone: 32 threads that all spin 100 us after a fork 5.0-5.6 M / 3.2-3.6 M with 29 of 30 periods
+	// throttled — the setting round 3 first chose from runs of a few milliseconds, where it is the fastest —; 32 threads,
+	// no spinning 7.1-8.1 / 4.4-5.2; 16 threads, all spinning 5.9-7.1 / 5.2-5.8; 24 threads of which at most 2 spin
+	// 8.4 / 6.0, nothing throttled).  The spinner limit is the pool's (thread_pool.hpp).
 	if (const char *e = std::getenv("VG_THREADS"))
 		if (int v = std::atoi(e); v > 0)
 			return (unsigned)v;
 	static const unsigned budget = cpu_budget();
-	return std::max(1u, std::min(2 * budget, 64u));
+	return std::max(1u, std::min(budget + budget / 2, 64u));
 }
 
 ThreadPool &FontManager::pool()

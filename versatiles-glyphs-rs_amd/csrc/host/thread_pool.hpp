@@ -10,13 +10,17 @@
 //  * the join waits for the ITEMS, not for the workers: whoever is awake does the work, and the caller returns when
 //    the last item is done (rounds 1-2 waited until every worker had checked in, i.e. for the slowest of 15-31
 //    futex wake-ups, 50-90 us per fork when the workers had gone to sleep behind a device wait);
-//  * workers poll the word for ~100 us after a fork before they sleep on the condition variable (the next fork
-//    usually follows within microseconds), and the caller polls the count of finished items before it sleeps.
+//  * a few workers (max_spinners) poll the word for ~100 us after a fork before they sleep on the condition variable
+//    (the next fork usually follows within microseconds), the others sleep at once; the caller polls the count of
+//    finished items before it sleeps.
 #pragma once
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <pthread.h>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -83,10 +87,18 @@ public:
 	}
 
 private:
-	// busy-wait for `ready` for at most ~100 us; true when it came
+	// busy-wait for `ready` for at most ~100 us (VG_POOL_SPIN_US: measurement switch); true when it came
+	static long spin_us()
+	{
+		static const long us = [] {
+			const char *e = std::getenv("VG_POOL_SPIN_US");
+			return e ? std::max(0l, std::atol(e)) : 100l;
+		}();
+		return us;
+	}
 	template <class Ready> static bool poll(Ready ready)
 	{
-		const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+		const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us());
 		for (;;) {
 			for (int i = 0; i < 64; i++) {
 				if (ready())
@@ -134,12 +146,32 @@ private:
 			}
 		}
 	}
+	// workers that may poll at the same time; the others go to sleep as soon as they run out of items.  Two or three hot
+	// workers (and the caller) pick the next fork up at once — enough for the short phases — while the rest costs no CPU
+	// time between forks: under a CPU quota every spinning thread is paid for (font_manager.cpp, worker_count)
+	unsigned max_spinners() const
+	{
+		static const long env = [] {
+			const char *e = std::getenv("VG_POOL_SPINNERS"); // (measurement switch)
+			return e ? std::max(0l, std::atol(e)) : -1l;
+		}();
+		return env >= 0 ? (unsigned)env : std::max(2u, n_ / 12u);
+	}
 	void loop(unsigned id)
 	{
+		{
+			char name[16];
+			std::snprintf(name, sizeof name, "vg-pool-%u", id);
+			pthread_setname_np(pthread_self(), name);
+		}
 		uint32_t seen = 0;
 		for (;;) {
 			auto moved = [&] { return gen_of(state_.load(std::memory_order_acquire)) != seen; };
-			if (!poll(moved)) {
+			bool came = false;
+			if (spinners_.fetch_add(1, std::memory_order_relaxed) < max_spinners())
+				came = poll(moved);
+			spinners_.fetch_sub(1, std::memory_order_relaxed);
+			if (!came) {
 				std::unique_lock<std::mutex> l(mu_);
 				sleepers_.fetch_add(1, std::memory_order_seq_cst);
 				cv_.wait(l, [&] { return gen_of(state_.load(std::memory_order_seq_cst)) != seen; });
@@ -164,7 +196,7 @@ private:
 	std::atomic<uint32_t> done_{0};
 	std::atomic<bool> failed_{false}, stop_{false};
 	std::string error_;
-	std::atomic<unsigned> sleepers_{0};
+	std::atomic<unsigned> sleepers_{0}, spinners_{0};
 };
 
 } // namespace vg

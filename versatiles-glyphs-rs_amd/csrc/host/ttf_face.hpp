@@ -29,6 +29,7 @@ struct OutlineBuilder {
 	virtual void quad_to(float x1, float y1, float x, float y) = 0;
 	virtual void curve_to(float x1, float y1, float x2, float y2, float x, float y) = 0;
 	virtual void close() = 0;
+	static constexpr bool kRawCursor = false; // (the glyf walk's packed recorder in ttf_face.cpp is the sink that has one)
 };
 
 // Non-owning big-endian byte view with checked reads.
