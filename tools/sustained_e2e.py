@@ -77,6 +77,8 @@ def main():
     print(f"  cpu.stat: {d.get('usage_usec', 0) / 1e6 / wall:.1f} CPUs used on average, {d.get('nr_throttled', 0)} of {d.get('nr_periods', 0)} periods throttled, "
           f"{d.get('throttled_usec', 0) / 1e3:.0f} ms throttled (summed over threads)")
 
+    tm = mgr.timings()
+    print("  phases of the last run (ms): " + " ".join(f"{k[:-2]}={v * 1e3:.3f}" for k, v in tm.items() if k.endswith("_s")))
     th1 = thread_times()
     by = {}
     for tid, (name, secs) in th1.items():
