@@ -20,5 +20,12 @@ def test_thread_pool_stress(tmp_path, flags):
     if built.returncode != 0 and "-fsanitize=thread" in flags:
         pytest.skip("ThreadSanitizer runtime not available: " + built.stderr[-200:])
     assert built.returncode == 0, built.stderr
-    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=240)
-    assert run.returncode == 0 and run.stdout.startswith("OK") and "ThreadSanitizer" not in run.stderr, run.stdout + run.stderr[-2000:]
+    import os
+    # default policy (a few workers poll, the others sleep at once), nobody polls, everybody polls
+    for spinners in (None, "0", "999"):
+        env = dict(os.environ)
+        if spinners is not None:
+            env["VG_POOL_SPINNERS"] = spinners
+        run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=240, env=env)
+        assert run.returncode == 0 and run.stdout.startswith("OK") and "ThreadSanitizer" not in run.stderr, \
+            f"spinners={spinners}: " + run.stdout + run.stderr[-2000:]
