@@ -46,6 +46,8 @@ typedef struct {
 typedef struct {
 	double tessellate_s, pack_s, device_s, encode_s, write_s, total_s;
 	uint64_t blocks, glyphs, rasters, pixels, segments, pbf_bytes;
+	uint64_t glyf_groups;    /* submissions whose glyphs the device decoded from their `glyf` arrays */
+	uint64_t glyf_fallbacks; /* of which the device refused (a malformed entry) and the host's reader recorded again */
 } vg_timings;
 
 /* Writer sink (src/writer/mod.rs:10-19): is_dir=1 for write_directory. Return 0, or
@@ -80,6 +82,11 @@ void vg_manager_set_device_front_end(vg_manager *m, int on);
  * host writes the ~20 bytes around it (src/protobuf/glyphs.rs:66-70 without a second copy of the bitmaps); 0: bitmaps
  * packed back to back, blocks encoded afterwards.  Same bytes either way. */
 void vg_manager_set_in_place_pbf(vg_manager *m, int on);
+/* glyf fonts through the device front-end: 1 (default) = the glyphs' `glyf` arrays are copied as they stand and decoded on
+ * the device (vgsdf_outlines_submit_glyf: what ttf-parser's Face::outline_glyph does for renderer.rs:110, replayed there),
+ * 0 = the host's reader records the callbacks (CFF / CFF2 fonts always take that way; so does a batch in which the device
+ * finds a malformed entry).  Same bytes either way. */
+void vg_manager_set_glyf_on_device(vg_manager *m, int on);
 int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
 int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
 /* manager.rs:39-53: the file's name table decides the font id (family/width/weight/style ->
@@ -167,6 +174,13 @@ typedef struct vg_outline_batch vg_outline_batch;
 vg_outline_batch *vg_manager_record_outlines(const vg_manager *m, const char *font_id);
 int vg_outline_batch_view(const vg_outline_batch *b, vgsdf_outlines *view, const uint32_t **ids, const uint32_t **advances);
 void vg_outline_batch_free(vg_outline_batch *b);
+/* The same for the device's glyf decoder (fonts whose glyphs all have `glyf` outlines; NULL otherwise): nothing is decoded
+ * on the host, every glyph's simple glyphs are listed as parts with their arrays copied as they stand — the argument of
+ * vgsdf_outlines_submit_glyf (pbf_pre / pbf_fix NULL).  Valid until vg_glyf_batch_free. */
+typedef struct vg_glyf_batch vg_glyf_batch;
+vg_glyf_batch *vg_manager_record_glyf_parts(const vg_manager *m, const char *font_id);
+int vg_glyf_batch_view(const vg_glyf_batch *b, vgsdf_outlines_glyf *view, const uint32_t **ids, const uint32_t **advances);
+void vg_glyf_batch_free(vg_glyf_batch *b);
 
 /* Hand-encoder of the glyphs PBF (src/protobuf/glyphs.rs:66-70) for already rendered
  * glyphs; bitmaps[i] may be NULL when !has_bitmap. Returns needed size. */

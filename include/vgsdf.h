@@ -32,7 +32,8 @@ typedef enum {
 	VGSDF_OK = 0,
 	VGSDF_E_ARG = -1, /* NULL / inconsistent batch */
 	VGSDF_E_HIP = -2, /* HIP runtime error (no device, launch failure, ...) */
-	VGSDF_E_OOM = -3  /* device or pinned-host allocation failed */
+	VGSDF_E_OOM = -3, /* device or pinned-host allocation failed */
+	VGSDF_E_GLYF = -4 /* vgsdf_outlines_submit_glyf: a malformed `glyf` entry in the batch — record it with a host reader instead */
 } vgsdf_status;
 
 /* One context per (host thread, GPU): owns a HIP stream, device buffers and pinned
@@ -201,6 +202,42 @@ typedef struct {
 	const uint8_t *pbf_fix;  /* [n_glyphs] or NULL */
 } vgsdf_outlines_packed;
 int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in, uint8_t *out_bitmaps, size_t out_capacity);
+/* The same front-end fed with the glyphs' `glyf` entries themselves: the host only looks glyphs up (cmap, loca, the
+ * component records of composite glyphs) and copies bytes; the device replays ttf-parser's walk of every simple glyph
+ * (glyf.rs parse_simple_outline + Builder: flag runs, short / repeated coordinates, wrapping i16 sums, implied on-curve
+ * midpoints, the closing curve of a contour) and produces the callbacks Face::outline_glyph would deliver
+ * (/root/reference/src/render/renderer.rs:110), then runs on as above.  One PART per simple glyph:
+ *   bytes[byte_off .. +byte_len)  endPtsOfContours[n_contours] (big-endian u16, as in the font) followed by the entry's
+ *                                 flags / xCoordinates / yCoordinates exactly as they stand in the font (the bytes from behind
+ *                                 the instructions to the end of the entry); byte_off a multiple of 4
+ *   a b c d e f                   the transform ttf-parser has accumulated for the component (x' = a x + c y + e,
+ *                                 y' = b x + d y + f, in f32); plain = 1 for the identity (a simple glyph drawn as itself)
+ *   cmd_at, cmd_cap               its command slots: cmd_cap >= points + 3 * contours of the entry (what its end points say);
+ *                                 the parts tile [0, cmd_off[n_glyphs]) in order, glyph g owns [cmd_off[g], cmd_off[g + 1])
+ * A glyph without outline has no part and no slots.  Slots a part does not need are filled with close() callbacks, which
+ * do nothing on the empty ring behind a contour's own close().  An entry whose arrays do not fit its bytes or its slots
+ * (ttf-parser returns None for such a glyph and, in a composite, skips the components behind it) fails the whole batch with
+ * VGSDF_E_GLYF in vgsdf_outlines_wait: the caller records that batch with its host reader and submits commands instead.
+ * In ONE block from vgsdf_host_alloc() in the order scale | shift_x | cmd_off | (pad to a multiple of 8 bytes) | parts | bytes
+ * [| pbf_pre | pbf_fix] the batch is uploaded with a single copy.  pbf_pre / pbf_fix as in vgsdf_outlines_packed. */
+typedef struct {
+	uint32_t byte_off, byte_len;
+	uint32_t cmd_at, cmd_cap;
+	uint32_t n_contours; /* > 0 */
+	uint32_t plain;
+	float a, b, c, d, e, f;
+} vgsdf_glyf_part;
+typedef struct {
+	uint32_t n_glyphs, n_parts, n_bytes; /* n_bytes a multiple of 4 */
+	const uint32_t *cmd_off;      /* [n_glyphs + 1] command slots, cmd_off[0] = 0 */
+	const vgsdf_glyf_part *parts; /* [n_parts] */
+	const uint8_t *bytes;         /* [n_bytes] */
+	const double *scale;          /* [n_glyphs] */
+	const double *shift_x;        /* [n_glyphs] */
+	const uint32_t *pbf_pre;      /* [n_glyphs] or NULL */
+	const uint8_t *pbf_fix;       /* [n_glyphs] or NULL */
+} vgsdf_outlines_glyf;
+int vgsdf_outlines_submit_glyf(vgsdf_ctx *ctx, const vgsdf_outlines_glyf *in, uint8_t *out_bitmaps, size_t out_capacity);
 int vgsdf_outlines_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, uint64_t *n_segments, int *rendered);
 /* Between submit and wait: blocks until the front-end's results are on the host — they leave the device right behind the
  * plan kernel, on a stream of their own, while flattening and raster are still running — and reports the rects and

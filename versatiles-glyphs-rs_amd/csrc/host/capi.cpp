@@ -32,6 +32,10 @@ struct vg_outline_batch {
 	vg::OutlineBatch b;
 	std::vector<uint32_t> ids, advances;
 };
+struct vg_glyf_batch {
+	vg::GlyfPartsBatch b;
+	std::vector<uint32_t> ids, advances;
+};
 struct vg_glyph_batch {
 	vg::PackedBatch b;
 	std::vector<uint32_t> ids;
@@ -108,6 +112,7 @@ vg_manager *vg_manager_new(int parallel) { return new vg_manager(parallel != 0);
 void vg_manager_free(vg_manager *m) { delete m; }
 void vg_manager_set_device_front_end(vg_manager *m, int on) { m->m.set_device_front_end(on != 0); }
 void vg_manager_set_in_place_pbf(vg_manager *m, int on) { m->m.set_in_place_pbf(on != 0); }
+void vg_manager_set_glyf_on_device(vg_manager *m, int on) { m->m.set_glyf_on_device(on != 0); }
 void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch)
 {
 	m->m.set_threads(threads);
@@ -387,7 +392,7 @@ int vg_manager_timings(const vg_manager *m, vg_timings *out)
 {
 	const vg::RenderTimings &t = m->m.last_timings();
 	*out = vg_timings{t.tessellate_s, t.pack_s, t.device_s, t.encode_s, t.write_s, t.total_s, t.blocks,
-	                  t.glyphs,       t.rasters,  t.pixels,   t.segments, t.pbf_bytes};
+	                  t.glyphs,       t.rasters,  t.pixels,   t.segments, t.pbf_bytes,  t.glyf_groups, t.glyf_fallbacks};
 	return 0;
 }
 long vg_manager_render_block(vg_manager *m, vg_renderer *r, const char *font_id, uint32_t start, uint8_t *out,
@@ -498,6 +503,48 @@ int vg_outline_batch_view(const vg_outline_batch *b, vgsdf_outlines *view, const
 	return 0;
 }
 void vg_outline_batch_free(vg_outline_batch *b) { delete b; }
+
+vg_glyf_batch *vg_manager_record_glyf_parts(const vg_manager *m, const char *font_id)
+{
+	try {
+		auto *b = new vg_glyf_batch();
+		std::string err;
+		if (!m->m.record_glyf_parts(font_id, b->b, &err)) {
+			delete b;
+			g_err = err;
+			return nullptr;
+		}
+		for (const vg::GlyphJob &j : b->b.jobs) {
+			b->ids.push_back(j.id);
+			b->advances.push_back(j.advance);
+		}
+		return b;
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+int vg_glyf_batch_view(const vg_glyf_batch *b, vgsdf_outlines_glyf *view, const uint32_t **ids, const uint32_t **advances)
+{
+	static_assert(sizeof(vg::GlyfPart) == sizeof(vgsdf_glyf_part), "same record");
+	const vg::GlyfPartsBatch &g = b->b;
+	view->n_glyphs = (uint32_t)g.jobs.size();
+	view->n_parts = (uint32_t)g.parts.size();
+	view->n_bytes = (uint32_t)g.bytes.size();
+	view->cmd_off = g.slot_off.data();
+	view->parts = reinterpret_cast<const vgsdf_glyf_part *>(g.parts.data());
+	view->bytes = g.bytes.data();
+	view->scale = g.scale.data();
+	view->shift_x = g.shift_x.data();
+	view->pbf_pre = nullptr;
+	view->pbf_fix = nullptr;
+	if (ids)
+		*ids = b->ids.data();
+	if (advances)
+		*advances = b->advances.data();
+	return 0;
+}
+void vg_glyf_batch_free(vg_glyf_batch *b) { delete b; }
 
 long vg_pbf_encode(const char *name, const char *range, const vg_pbf_glyph *glyphs, const uint8_t *const *bitmaps,
                    int n, uint8_t *out, size_t cap)

@@ -474,6 +474,28 @@ bool FontManager::record_outlines(const std::string &font_id, OutlineBatch &out,
 	return true;
 }
 
+bool FontManager::record_glyf_parts(const std::string &font_id, GlyfPartsBatch &out, std::string *err) const
+{
+	auto it = fonts().find(font_id);
+	if (it == fonts().end()) {
+		if (err)
+			*err = "unknown font id " + font_id;
+		return false;
+	}
+	out.clear();
+	for (const GlyphBlock &b : task_blocks(it->first, it->second)) {
+		if (!b.all_glyf) {
+			if (err)
+				*err = "font " + font_id + " has glyphs without glyf outlines (CFF / CFF2): the device decodes glyf entries only";
+			return false;
+		}
+		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+			if (const FontFileEntry *f = b.glyphs[ci])
+				Renderer::record_parts(f->face(), b.start_index + ci, out);
+	}
+	return true;
+}
+
 // ---- glyph-level sharding ---------------------------------------------------------------
 namespace {
 
@@ -772,6 +794,7 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 	for (auto &c : children_) {
 		c->device_front_end_ = device_front_end_;
 		c->in_place_pbf_ = in_place_pbf_;
+		c->glyf_on_device_ = glyf_on_device_;
 		c->batch_blocks_ = batch_blocks_;
 		c->batch_blocks_set_ = batch_blocks_set_;
 		c->set_threads(per_lane);
@@ -843,6 +866,8 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 		timings_.rasters += ct.rasters;
 		timings_.pixels += ct.pixels;
 		timings_.segments += ct.segments;
+		timings_.glyf_groups += ct.glyf_groups;
+		timings_.glyf_fallbacks += ct.glyf_fallbacks;
 	}
 	renderer.reduce_counters(reduced_);
 	if (std::memcmp(reduced_, want, sizeof want) != 0)
@@ -876,8 +901,130 @@ void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const 
 // Host half of the device front-end for tasks [G.g0, G.g1): look the glyphs up, record their outline
 // commands on the pool (64-code-point slices, worker-local buffers), merge in task order into the
 // group's page-locked arrays.
-void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
+// The group's glyphs for the device's glyf decoder (vgsdf_outlines_glyf): the workers look every glyph up and copy the
+// arrays of its simple glyphs as they stand — no point is decoded on the host (0.56 us of CPU per glyph with the
+// recorder below, ~0.1 here).  Same slices, same merge in task order as fe_record.
+void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 {
+	constexpr uint32_t kSlice = 64;
+	ThreadPool &tp = pool();
+	const double t0 = now_s();
+	std::vector<OSlice> &slices = G.slices;
+	slices.clear();
+	G.slice_ci.clear();
+	for (size_t t = G.g0; t < G.g1; t++) {
+		if (tasks[t].block.is_empty())
+			continue;
+		for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += kSlice) {
+			OSlice s;
+			s.task = (uint32_t)t;
+			slices.push_back(s);
+			G.slice_ci.push_back(c);
+		}
+	}
+	for (Worker &w : workers_)
+		w.plocal.clear();
+	tp.run(slices.size(), [&](size_t i, unsigned wid) {
+		OSlice &s = slices[i];
+		Worker &w = workers_[wid];
+		s.worker = wid;
+		s.job0 = (uint32_t)w.plocal.jobs.size();
+		const GlyphBlock &blk = tasks[s.task].block;
+		for (uint32_t ci = G.slice_ci[i]; ci < G.slice_ci[i] + kSlice; ci++)
+			if (const FontFileEntry *f = blk.glyphs[ci])
+				Renderer::record_parts(f->face(), blk.start_index + ci, w.plocal);
+		s.job1 = (uint32_t)w.plocal.jobs.size();
+	});
+	const double t1 = now_s();
+	timings_.tessellate_s += t1 - t0;
+
+	// merge in task order: jobs, command slots, parts and bytes of a slice are contiguous in its worker's batch
+	uint32_t n_jobs = 0, n_slots = 0, n_parts = 0, n_bytes = 0;
+	G.slice_cmd.resize(slices.size());
+	G.slice_part.resize(slices.size());
+	G.slice_byte.resize(slices.size());
+	auto byte_at = [](const GlyfPartsBatch &l, uint32_t part) { // first byte of `part` (the end of the store behind the last one)
+		return part < l.parts.size() ? l.parts[part].byte_off : (uint32_t)l.bytes.size();
+	};
+	for (size_t i = 0; i < slices.size(); i++) {
+		OSlice &s = slices[i];
+		const GlyfPartsBatch &l = workers_[s.worker].plocal;
+		s.g_job = n_jobs;
+		G.slice_cmd[i] = n_slots;
+		G.slice_part[i] = n_parts;
+		G.slice_byte[i] = n_bytes;
+		n_jobs += s.job1 - s.job0;
+		n_slots += l.slot_off[s.job1] - l.slot_off[s.job0];
+		n_parts += l.part_off[s.job1] - l.part_off[s.job0];
+		n_bytes += byte_at(l, l.part_off[s.job1]) - byte_at(l, l.part_off[s.job0]);
+	}
+	G.n_jobs = n_jobs;
+	MergedOutlines &m = G.m;
+	m.jobs.resize(n_jobs);
+	G.in_place = in_place_pbf_;
+	m.layout_glyf(n_jobs, n_parts, n_bytes, G.in_place);
+	m.cmd_off[0] = 0;
+	tp.run(slices.size(), [&](size_t i, unsigned) {
+		const OSlice &s = slices[i];
+		const GlyfPartsBatch &l = workers_[s.worker].plocal;
+		const uint32_t p0 = l.part_off[s.job0], p1 = l.part_off[s.job1], s0 = l.slot_off[s.job0];
+		const uint32_t b0 = byte_at(l, p0), b1 = byte_at(l, p1);
+		if (b1 > b0)
+			std::memcpy(m.glyf_bytes + G.slice_byte[i], l.bytes.data() + b0, b1 - b0);
+		for (uint32_t k = p0; k < p1; k++) {
+			vgsdf_glyf_part q;
+			static_assert(sizeof q == sizeof l.parts[k], "same record");
+			std::memcpy(&q, &l.parts[k], sizeof q);
+			q.byte_off = G.slice_byte[i] + (l.parts[k].byte_off - b0);
+			q.cmd_at = G.slice_cmd[i] + (l.parts[k].cmd_at - s0);
+			m.parts[G.slice_part[i] + (k - p0)] = q;
+		}
+		for (uint32_t j = s.job0; j < s.job1; j++) {
+			const uint32_t g = s.g_job + (j - s.job0);
+			m.jobs[g] = l.jobs[j];
+			m.scale[g] = l.scale[j];
+			m.shift_x[g] = l.shift_x[j];
+			if (m.pbf_fix) {
+				m.pbf_pre[g] = 0;
+				m.pbf_fix[g] = pbf_fix_of(l.jobs[j].id, l.jobs[j].advance);
+			}
+			m.cmd_off[g + 1] = G.slice_cmd[i] + (l.slot_off[j + 1] - s0);
+		}
+	});
+	fe_layout_common(tasks, G);
+	timings_.pack_s += now_s() - t1;
+}
+
+// jobs of a task are contiguous in the merged batch: [task_g0[t], task_g0[t + 1]); the first glyph of a block leaves room
+// for the block's file + fontstack header in front of its entry
+void FontManager::fe_layout_common(const std::vector<Todo> &tasks, FeGroup &G)
+{
+	MergedOutlines &m = G.m;
+	const std::vector<OSlice> &slices = G.slices;
+	G.task_g0.assign(G.g1 - G.g0 + 1, G.n_jobs);
+	size_t t_next = 0;
+	for (size_t i = 0; i < slices.size(); i++)
+		for (; t_next <= slices[i].task - G.g0; t_next++)
+			G.task_g0[t_next] = slices[i].g_job;
+	if (m.pbf_pre)
+		for (size_t t = G.g0; t < G.g1; t++) {
+			const uint32_t a = G.task_g0[t - G.g0], b = G.task_g0[t - G.g0 + 1];
+			if (a < b)
+				m.pbf_pre[a] = kPbfHeadRoom + pbf_block_fields(tasks[t].name->size(), tasks[t].block.range().size());
+		}
+}
+
+void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool allow_glyf)
+{
+	if (allow_glyf && glyf_on_device_) {
+		bool all_glyf = true;
+		for (size_t t = G.g0; t < G.g1 && all_glyf; t++)
+			all_glyf = tasks[t].block.all_glyf;
+		if (all_glyf) {
+			fe_record_glyf(tasks, G);
+			return;
+		}
+	}
 	constexpr uint32_t kSlice = 64;
 	ThreadPool &tp = pool();
 	const double t0 = now_s();
@@ -929,14 +1076,6 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 	m.jobs.resize(n_jobs);
 	G.in_place = in_place_pbf_;
 	m.layout(n_jobs, n_cmds, n_floats, G.in_place);
-	// jobs of a task are contiguous in the merged batch: [task_g0[t], task_g0[t + 1])
-	G.task_g0.assign(G.g1 - G.g0 + 1, n_jobs);
-	{
-		size_t t_next = 0;
-		for (size_t i = 0; i < slices.size(); i++)
-			for (; t_next <= slices[i].task - G.g0; t_next++)
-				G.task_g0[t_next] = slices[i].g_job;
-	}
 	m.cmd_off[0] = 0;
 	m.dat_off[0] = 0;
 	tp.run(slices.size(), [&](size_t i, unsigned) {
@@ -961,12 +1100,7 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G)
 			m.dat_off[g + 1] = G.slice_dat[i] + (l.dat_off[j + 1] - ld0);
 		}
 	});
-	if (m.pbf_pre) // the first glyph of a block leaves room for the block's file + fontstack header in front of its entry
-		for (size_t t = G.g0; t < G.g1; t++) {
-			const uint32_t a = G.task_g0[t - G.g0], b = G.task_g0[t - G.g0 + 1];
-			if (a < b)
-				m.pbf_pre[a] = kPbfHeadRoom + pbf_block_fields(tasks[t].name->size(), tasks[t].block.range().size());
-		}
+	fe_layout_common(tasks, G);
 	timings_.pack_s += now_s() - t1;
 }
 
@@ -1164,7 +1298,11 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		fe_record(tasks, G);
 		const double t = now_s();
 		if (G.n_jobs) {
-			renderer.submit_outlines((int)(k & 1), G.m.view(), G.out);
+			if (G.m.glyf) {
+				renderer.submit_outlines((int)(k & 1), G.m.view_glyf(), G.out);
+				timings_.glyf_groups++;
+			} else
+				renderer.submit_outlines((int)(k & 1), G.m.view(), G.out);
 			in_flight[k & 1] = true;
 		}
 		timings_.device_s += now_s() - t;
@@ -1186,7 +1324,18 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		}
 		if (in_flight[k & 1]) {
 			in_flight[k & 1] = false;
-			renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs, G.in_place ? &G.pbf_at : nullptr);
+			try {
+				renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs, G.in_place ? &G.pbf_at : nullptr);
+			} catch (const GlyfEntryError &) {
+				// a malformed `glyf` entry somewhere in the group: ttf-parser's rules for such glyphs (None for the glyph, the
+				// rest of a composite skipped) are the host reader's — the group is recorded there and rendered again, now
+				early = false;
+				timings_.glyf_fallbacks++;
+				fe_record(tasks, G, false);
+				t = now_s();
+				renderer.submit_outlines((int)(k & 1), G.m.view(), G.out);
+				renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs, G.in_place ? &G.pbf_at : nullptr);
+			}
 		}
 		timings_.device_s += now_s() - t;
 		if (G.in_place && G.n_jobs) {

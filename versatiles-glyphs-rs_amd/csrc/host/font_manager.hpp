@@ -60,6 +60,7 @@ struct GlyphBlock {
 	uint32_t start_index = 0;
 	std::array<const FontFileEntry *, GLYPH_BLOCK_SIZE> glyphs{}; // nullptr = unmapped
 	uint32_t count = 0;
+	bool all_glyf = true; // every glyph of the block comes from a file with `glyf` outlines (the device can decode them)
 
 	// glyph_block.rs:34-36: first provider wins
 	void set_glyph_font(uint8_t char_index, const FontFileEntry *font)
@@ -67,6 +68,7 @@ struct GlyphBlock {
 		if (!glyphs[char_index]) {
 			glyphs[char_index] = font;
 			count++;
+			all_glyf = all_glyf && font->face().has_glyf_outlines();
 		}
 	}
 	size_t len() const { return count; }
@@ -130,6 +132,7 @@ struct GlyphShard {
 struct RenderTimings {
 	double tessellate_s = 0, pack_s = 0, device_s = 0, encode_s = 0, write_s = 0, total_s = 0;
 	uint64_t blocks = 0, glyphs = 0, rasters = 0, pixels = 0, segments = 0, pbf_bytes = 0;
+	uint64_t glyf_groups = 0, glyf_fallbacks = 0; // device front-end: groups decoded from `glyf` arrays / re-recorded on the host
 };
 
 class FontManager {
@@ -200,6 +203,11 @@ public:
 	// the finished PBF has it and the host writes the ~20 bytes around it; false: bitmaps packed back to back, blocks
 	// encoded afterwards (one more copy of every bitmap).  Same bytes either way.
 	void set_in_place_pbf(bool on) { in_place_pbf_ = on; }
+	// glyf fonts through the device front-end: true (default; VG_GLYF_ON_DEVICE=0 in the environment changes it) = the
+	// device decodes the glyphs' `glyf` arrays, false = the host's reader records the callbacks.  Same bytes either way.
+	void set_glyf_on_device(bool on) { glyf_on_device_ = on; }
+	// every glyph of a font id in the form the device's glyf decoder takes (glyf fonts only; tests, inspection)
+	bool record_glyf_parts(const std::string &font_id, GlyfPartsBatch &out, std::string *err) const;
 
 private:
 	struct Todo {
@@ -226,6 +234,7 @@ private:
 		TessScratch scratch;
 		GlyphBatch local;
 		PackedOutlineBatch olocal;
+		GlyfPartsBatch plocal;
 		char pad[128];
 	};
 	// One process, N devices (renderer.n_devices() > 1): the glyphs of every font are dealt to the device lanes by
@@ -267,6 +276,7 @@ private:
 		size_t g0 = 0, g1 = 0;
 		std::vector<OSlice> slices;
 		std::vector<uint32_t> slice_ci, slice_cmd, slice_dat;
+		std::vector<uint32_t> slice_part, slice_byte; // glyf form: first part / first byte of every slice in the merged batch
 		MergedOutlines m;
 		std::vector<vgsdf_rect> rects;
 		std::vector<uint64_t> pbf_at;       // in-place assembly: position of every job's bitmap in `out`
@@ -284,11 +294,19 @@ private:
 		uint32_t n_jobs = 0;
 	};
 	FeGroup fe_group_[2]; // two groups in flight: one on the GPU, one being recorded / encoded
-	void fe_record(const std::vector<Todo> &tasks, FeGroup &G);
+	void fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool allow_glyf = true);
+	void fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G);
+	void fe_layout_common(const std::vector<Todo> &tasks, FeGroup &G); // task_g0, pbf_pre of the merged batch
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
 	void fe_assemble(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_write_pieces(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
+	static bool glyf_on_device_default()
+	{
+		const char *e = std::getenv("VG_GLYF_ON_DEVICE");
+		return !(e && e[0] == '0');
+	}
 	bool in_place_pbf_ = true;
+	bool glyf_on_device_ = glyf_on_device_default(); // glyf fonts: the device decodes the glyphs' arrays (VG_GLYF_ON_DEVICE=0 / set_glyf_on_device(false): the host does)
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here
 	bool parallel_;

@@ -317,6 +317,29 @@ bool Renderer::record(const Face &face, uint32_t index, PackedOutlineBatch &batc
 	return true;
 }
 
+bool Renderer::record_parts(const Face &face, uint32_t index, GlyfPartsBatch &batch)
+{
+	static_assert(sizeof(GlyfPart) == sizeof(vgsdf_glyf_part), "the host's part record is the ABI's, field for field");
+	if (index > 0x10FFFF || (index >= 0xD800 && index <= 0xDFFF)) // renderer.rs:104
+		return false;
+	const auto glyph_id = face.glyph_index(index); // :106
+	if (!glyph_id)
+		return false;
+	const double scale = (double)GLYPH_SIZE / (double)face.units_per_em(); // :107
+	(void)face.glyph_parts(*glyph_id, batch.parts, batch.bytes, batch.slots); // :109-111: the outline, undecoded
+	const double advance_float = (double)face.glyph_hor_advance(*glyph_id).value_or(0) * scale * 0.95; // :115
+	const uint32_t advance = to_u32(std::round(advance_float));                                          // :116
+	GlyphJob job;
+	job.id = index;
+	job.advance = advance;
+	batch.jobs.push_back(job);
+	batch.slot_off.push_back(batch.slots);
+	batch.part_off.push_back((uint32_t)batch.parts.size());
+	batch.scale.push_back(scale);
+	batch.shift_x.push_back(((double)advance - advance_float) / 2.0); // :130
+	return true;
+}
+
 vgsdf_ctx *Renderer::lane_ctx(int lane) const
 {
 	if (lane == 0)
@@ -342,6 +365,27 @@ void Renderer::submit_outlines(int lane, const vgsdf_outlines_packed &v, HostBuf
 		std::lock_guard<std::mutex> lock(mu_);
 		if (vgsdf_outlines_submit_packed(c, &v, out.data(), out.capacity()) != VGSDF_OK)
 			throw std::runtime_error(std::string("vgsdf_outlines_submit_packed: ") + vgsdf_last_error(c));
+	} catch (...) {
+		lane_mu_[lane].unlock();
+		throw;
+	}
+}
+
+void Renderer::submit_outlines(int lane, const vgsdf_outlines_glyf &v, HostBuffer<uint8_t> &out) const
+{
+	if (mode_ != Mode::Hip)
+		throw std::runtime_error("render_outlines needs the HIP renderer (the device front-end has no CPU form)");
+	lane &= 1;
+	vgsdf_ctx *c = lane_ctx(lane);
+	lane_mu_[lane].lock();
+	// one submission: the raster writes into `out` as it stands (capacity kept from earlier groups; first guess
+	// 448 bytes per glyph, the average of the fixture fonts) — a second step in wait only when that was too small
+	try {
+		if (out.capacity() == 0)
+			out.ensure((size_t)v.n_glyphs * 480 + 16384);
+		std::lock_guard<std::mutex> lock(mu_);
+		if (vgsdf_outlines_submit_glyf(c, &v, out.data(), out.capacity()) != VGSDF_OK)
+			throw std::runtime_error(std::string("vgsdf_outlines_submit_glyf: ") + vgsdf_last_error(c));
 	} catch (...) {
 		lane_mu_[lane].unlock();
 		throw;
@@ -385,8 +429,11 @@ void Renderer::wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffe
 	std::unique_lock<std::mutex> lock(mu_, std::defer_lock);
 	if (lane == 0)
 		lock.lock();
-	if (vgsdf_outlines_wait(c, rects.data(), &out_bytes, &n_segments, &rendered) != VGSDF_OK)
+	if (const int rc = vgsdf_outlines_wait(c, rects.data(), &out_bytes, &n_segments, &rendered); rc != VGSDF_OK) {
+		if (rc == VGSDF_E_GLYF)
+			throw GlyfEntryError(std::string("vgsdf_outlines_wait: ") + vgsdf_last_error(c));
 		throw std::runtime_error(std::string("vgsdf_outlines_wait: ") + vgsdf_last_error(c));
+	}
 	if (!rendered && out_bytes) {
 		out.ensure((size_t)out_bytes + 1);
 		if (vgsdf_outlines_render(c, out.data()) != VGSDF_OK)

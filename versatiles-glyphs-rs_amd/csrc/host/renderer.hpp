@@ -18,6 +18,7 @@
 #include <new>
 #include <mutex>
 #include <optional>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -195,6 +196,34 @@ struct PackedOutlineBatch {
 	}
 };
 
+// wait_outlines on a batch submitted in the glyf form: one of its `glyf` entries is malformed (VGSDF_E_GLYF) — the batch
+// has to be recorded on the host, where ttf-parser's rules for such glyphs are applied
+struct GlyfEntryError : std::runtime_error {
+	using std::runtime_error::runtime_error;
+};
+
+// What a worker records for the device's glyf decoder (vgsdf_outlines_glyf): per glyph its metrics and the parts — the
+// simple glyphs it is drawn from, their `glyf` arrays copied as they stand.  Offsets are relative to this batch.
+struct GlyfPartsBatch {
+	std::vector<GlyphJob> jobs;
+	std::vector<uint32_t> slot_off{0}, part_off{0}; // [jobs + 1] command slots / parts
+	std::vector<GlyfPart> parts;
+	std::vector<uint8_t> bytes;
+	std::vector<double> scale, shift_x;
+	uint32_t slots = 0;
+	void clear()
+	{
+		jobs.clear();
+		slot_off.assign(1, 0);
+		part_off.assign(1, 0);
+		parts.clear();
+		bytes.clear();
+		scale.clear();
+		shift_x.clear();
+		slots = 0;
+	}
+};
+
 // The merged batch handed to the device, in the compact upload form (vgsdf_outlines_packed: one kind byte per
 // command plus the coordinates its kind carries).  All arrays live back to back in ONE page-locked block, in the
 // order vgsdf.h names for a single-copy upload: scale | shift_x | cmd_off | dat_off | (pad to 8) | coords | kinds.
@@ -208,9 +237,53 @@ struct MergedOutlines {
 	uint8_t *kinds = nullptr;
 	uint32_t *pbf_pre = nullptr; // in-place PBF assembly (vgsdf.h): bytes reserved in front of a glyph's entry
 	uint8_t *pbf_fix = nullptr;  // ... and the lengths of its id / advance fields; NULL when `with_pbf` was false
+	// the glyf form (vgsdf_outlines_glyf) in the same block: scale | shift_x | cmd_off | (pad to 8) | parts | bytes [| pbf_pre | pbf_fix]
+	bool glyf = false;
+	vgsdf_glyf_part *parts = nullptr;
+	uint8_t *glyf_bytes = nullptr;
+	uint32_t n_parts = 0, n_glyf_bytes = 0;
+	void layout_glyf(uint32_t jobs_n, uint32_t parts_n, uint32_t bytes_n, bool with_pbf)
+	{
+		n_jobs = jobs_n;
+		n_parts = parts_n;
+		n_glyf_bytes = bytes_n; // (a multiple of 4: every part's bytes are padded)
+		glyf = true;
+		const size_t n = jobs_n;
+		const size_t o_shift = 8 * n, o_cmd = 16 * n;
+		const size_t o_parts = (o_cmd + 4 * (n + 1) + 7) & ~(size_t)7, o_bytes = o_parts + sizeof(vgsdf_glyf_part) * (size_t)parts_n;
+		const size_t o_pre = o_bytes + bytes_n, o_fix = o_pre + 4 * n;
+		blob.ensure((with_pbf ? o_fix + n : o_pre) + 16);
+		uint8_t *b = blob.data();
+		pbf_pre = with_pbf ? reinterpret_cast<uint32_t *>(b + o_pre) : nullptr;
+		pbf_fix = with_pbf ? b + o_fix : nullptr;
+		scale = reinterpret_cast<double *>(b);
+		shift_x = reinterpret_cast<double *>(b + o_shift);
+		cmd_off = reinterpret_cast<uint32_t *>(b + o_cmd);
+		dat_off = nullptr;
+		coords = nullptr;
+		kinds = nullptr;
+		parts = reinterpret_cast<vgsdf_glyf_part *>(b + o_parts);
+		glyf_bytes = b + o_bytes;
+	}
+	vgsdf_outlines_glyf view_glyf() const
+	{
+		vgsdf_outlines_glyf o;
+		o.n_glyphs = n_jobs;
+		o.n_parts = n_parts;
+		o.n_bytes = n_glyf_bytes;
+		o.cmd_off = cmd_off;
+		o.parts = parts;
+		o.bytes = glyf_bytes;
+		o.scale = scale;
+		o.shift_x = shift_x;
+		o.pbf_pre = pbf_pre;
+		o.pbf_fix = pbf_fix;
+		return o;
+	}
 	void layout(uint32_t jobs_n, uint32_t n_cmds, uint32_t n_floats, bool with_pbf = false)
 	{
 		n_jobs = jobs_n;
+		glyf = false;
 		const size_t n = jobs_n;
 		const size_t o_shift = 8 * n, o_cmd = 16 * n, o_dat = o_cmd + 4 * (n + 1);
 		const size_t o_coords = (o_dat + 4 * (n + 1) + 7) & ~(size_t)7, o_kinds = o_coords + 4 * (size_t)n_floats;
@@ -309,6 +382,9 @@ public:
 	// outline commands (renderer.rs:104-116,130); everything else happens on the GPU.
 	static bool record(const Face &face, uint32_t index, OutlineBatch &batch);
 	static bool record(const Face &face, uint32_t index, PackedOutlineBatch &batch); // the same into the compact form
+	// ... and for the device's glyf decoder: nothing is decoded, the glyph's simple glyphs are appended as parts
+	// (glyf fonts only: face.has_glyf_outlines())
+	static bool record_parts(const Face &face, uint32_t index, GlyfPartsBatch &batch);
 	// Device front-end + raster for a recorded batch: fills rects (one per job) and `out` with
 	// the bitmaps of the glyphs that have a raster, packed in job order.  Hip mode only.
 	void render_outlines(const vgsdf_outlines &batch, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out,
@@ -318,6 +394,7 @@ public:
 	// busy while it records the next batch and encodes the previous one.  `batch` (its command array) and `out`
 	// must stay untouched between the two calls; a lane is held from submit to wait.
 	void submit_outlines(int lane, const vgsdf_outlines_packed &batch, HostBuffer<uint8_t> &out) const;
+	void submit_outlines(int lane, const vgsdf_outlines_glyf &batch, HostBuffer<uint8_t> &out) const;
 	void wait_outlines(int lane, std::vector<vgsdf_rect> &rects, HostBuffer<uint8_t> &out, uint64_t &out_bytes,
 	                   uint64_t &n_segments, uint32_t n_glyphs, std::vector<uint64_t> *pbf_at = nullptr) const;
 	// Between the two: the front-end's results as soon as they are on the host, while the raster is still running

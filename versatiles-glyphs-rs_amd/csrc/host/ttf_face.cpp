@@ -658,7 +658,8 @@ template <class B> bool walk_simple(Bytes body, uint16_t n_contours, ContourEmit
 
 } // namespace
 
-template <class B> struct GlyfWalker {
+// PARTS: the sink does not take callbacks but every simple glyph as it stands (B::part): the device decodes it
+template <class B, bool PARTS> struct GlyfWalker {
 	const Face &face;
 	B &out;
 
@@ -671,8 +672,12 @@ template <class B> struct GlyfWalker {
 		if (n_contours > 0) {
 			if (glyph.size() < 10)
 				return false;
-			ContourEmitter<B> em(out, t);
-			return walk_simple(body, (uint16_t)n_contours, em);
+			if constexpr (PARTS) {
+				return out.part(body, (uint16_t)n_contours, t.a, t.b, t.c, t.d, t.e, t.f, t.identity());
+			} else {
+				ContourEmitter<B> em(out, t);
+				return walk_simple(body, (uint16_t)n_contours, em);
+			}
 		}
 		if (n_contours == 0 || glyph.size() < 10)
 			return n_contours == 0;
@@ -737,7 +742,7 @@ bool Face::outline_glyph(uint16_t gid, OutlineBuilder &builder) const
 	const auto g = glyph_data(gid);
 	if (!g)
 		return false;
-	GlyfWalker<OutlineBuilder> w{*this, builder};
+	GlyfWalker<OutlineBuilder, false> w{*this, builder};
 	return w.walk(*g, 0, Affine{});
 }
 
@@ -806,6 +811,59 @@ struct PackedSinkVirtual final : OutlineBuilder {
 };
 } // namespace
 
+namespace {
+// Sink of the parts walk: what walk_simple checks BEFORE it touches the flag / coordinate arrays is checked here, with
+// the same outcome (false: ttf-parser returns None, the walk of a composite stops); the arrays themselves are copied
+// as they stand and checked where they are decoded (a mismatch there fails the batch: vgsdf.h, VGSDF_E_GLYF).
+struct PartsSink {
+	std::vector<GlyfPart> &parts;
+	std::vector<uint8_t> &bytes;
+	uint32_t &slots;
+	bool part(Bytes body, uint16_t n_contours, float a, float b, float c, float d, float e, float f, bool plain)
+	{
+		if (!body.has(0, (size_t)n_contours * 2))
+			return false;
+		const uint16_t last_end = body.u16((size_t)(n_contours - 1) * 2);
+		if (last_end == 0xFFFF)
+			return false;
+		const uint32_t n_points = (uint32_t)last_end + 1;
+		if (n_points == 1)
+			return true; // a lone point yields nothing
+		size_t cur = (size_t)n_contours * 2;
+		if (!body.has(cur, 2))
+			return false;
+		cur += 2 + body.u16(cur); // instructions: not needed on the device
+		if (cur > body.size())
+			return false;
+		GlyfPart p;
+		p.byte_off = (uint32_t)bytes.size(); // (a multiple of 4: padded below)
+		p.byte_len = (uint32_t)((size_t)n_contours * 2 + (body.size() - cur));
+		p.cmd_at = slots;
+		p.cmd_cap = n_points + 3u * n_contours;
+		p.n_contours = n_contours;
+		p.plain = plain ? 1u : 0u;
+		p.a = a, p.b = b, p.c = c, p.d = d, p.e = e, p.f = f;
+		const size_t at = bytes.size(), padded = ((size_t)p.byte_len + 3) & ~(size_t)3;
+		bytes.resize(at + padded); // (zero padding)
+		std::memcpy(bytes.data() + at, body.data(), (size_t)n_contours * 2);
+		std::memcpy(bytes.data() + at + (size_t)n_contours * 2, body.data() + cur, body.size() - cur);
+		slots += p.cmd_cap;
+		parts.push_back(p);
+		return true;
+	}
+};
+} // namespace
+
+bool Face::glyph_parts(uint16_t gid, std::vector<GlyfPart> &parts, std::vector<uint8_t> &bytes, uint32_t &slots) const
+{
+	const auto g = glyph_data(gid);
+	if (!g)
+		return false;
+	PartsSink sink{parts, bytes, slots};
+	GlyfWalker<PartsSink, true> w{*this, sink};
+	return w.walk(*g, 0, Affine{});
+}
+
 bool Face::outline_glyph_packed(uint16_t gid, std::vector<uint8_t> &kinds, std::vector<float> &coords) const
 {
 	PackedSink sink{kinds, coords};
@@ -817,7 +875,7 @@ bool Face::outline_glyph_packed(uint16_t gid, std::vector<uint8_t> &kinds, std::
 	if (!g)
 		return false;
 	PackedCursorSink cursor{kinds, coords};
-	GlyfWalker<PackedCursorSink> w{*this, cursor};
+	GlyfWalker<PackedCursorSink, false> w{*this, cursor};
 	return w.walk(*g, 0, Affine{});
 }
 

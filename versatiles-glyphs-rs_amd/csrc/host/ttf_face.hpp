@@ -32,6 +32,16 @@ struct OutlineBuilder {
 	static constexpr bool kRawCursor = false; // (the glyf walk's packed recorder in ttf_face.cpp is the sink that has one)
 };
 
+// One simple glyph of a (possibly composite) glyph in the form the device's glyf decoder takes (vgsdf_glyf_part of
+// include/vgsdf.h, field for field): the entry's end points + flag / coordinate arrays copied into a byte store, the
+// component transform ttf-parser has accumulated, and the command slots the entry may fill.
+struct GlyfPart {
+	uint32_t byte_off, byte_len;
+	uint32_t cmd_at, cmd_cap;
+	uint32_t n_contours, plain;
+	float a, b, c, d, e, f;
+};
+
 // Non-owning big-endian byte view with checked reads.
 class Bytes {
 public:
@@ -73,6 +83,10 @@ public:
 	// 0..4 = move / line / quad / curve / close + the coordinates the kind carries); glyf outlines are walked with the sink
 	// inlined (no virtual call per point).
 	bool outline_glyph_packed(uint16_t glyph_id, std::vector<uint8_t> &kinds, std::vector<float> &coords) const;
+	// glyf fonts only (has_glyf_outlines()): the same walk up to the simple glyphs, which are not decoded but appended as
+	// parts — their bytes to `bytes` (4-aligned), their command slots counted from `slots` on.  false: ttf-parser returns
+	// None at this point (parts appended so far stay, as the callbacks delivered so far would).
+	bool glyph_parts(uint16_t glyph_id, std::vector<GlyfPart> &parts, std::vector<uint8_t> &bytes, uint32_t &slots) const;
 	// ttf-parser's `tables().cmap.is_some()`; the reference refuses fonts without one (metadata.rs:104-107)
 	bool has_cmap() const { return has_cmap_; }
 	// glyph outlines this reader can emit: `glyf` + `loca`, or `CFF ` charstrings (ttf-parser's order: glyf first).
@@ -106,7 +120,7 @@ private:
 	std::shared_ptr<const CffTable> cff_;
 	size_t loca_entries_ = 0;
 
-	template <class B> friend struct GlyfWalker;
+	template <class B, bool PARTS> friend struct GlyfWalker;
 };
 
 } // namespace vg

@@ -42,7 +42,8 @@ struct PlanHeader {
 	uint32_t n_spans;              // entries of the work list (may exceed the capacity it was planned with)
 	uint32_t n_main;               // of which for the main kernel (they come first)
 	uint32_t error;                // bit 0: absurd input (a glyph beyond 2^28 points / 2^32 pixels, more than 2^32 - 1 segments);
-	                               // bit 1: a command kind that is none of the five callbacks
+	                               // bit 1: a command kind that is none of the five callbacks; bit 2: a cubic broke its depth bound;
+	                               // bit 3: dat_off does not match the kinds; bit 4: a malformed `glyf` entry (vgsdf_outlines_glyf)
 	uint32_t ok;                   // the raster launch enqueued behind the plan may run: no error, everything within the
 	                               // capacities and the grid it was planned against (outline_plan's last arguments)
 };
@@ -52,6 +53,10 @@ struct GlyphDesc;
 } // namespace vgsdf
 
 extern "C" {
+// parts: vgsdf_glyf_part records (include/vgsdf.h); writes the commands of every part into its slots of `cmds`;
+// error_flag bit 4: a malformed entry
+int vgsdf_glyf_decode(const void *parts, uint32_t n_parts, const uint8_t *bytes, vgsdf::OutlineCmd *cmds, uint32_t *error_flag,
+                      hipStream_t stream);
 // cmd_open: one byte per command (bit 0: ring open in front of it, bit 1: the glyph's scale is not positive finite)
 // error_flag: one zeroed word; bit 1 is raised for a command kind that is none of the five callbacks
 int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,

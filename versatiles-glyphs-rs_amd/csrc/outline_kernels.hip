@@ -1286,9 +1286,338 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------
+// glyf decode: thread per PART (one simple glyph of a — possibly composite — glyph, with the transform ttf-parser has
+// accumulated for it).  The host only looks glyphs up and copies each simple glyph's `glyf` arrays (end points of the
+// contours, then flags / x / y as they stand in the font, instructions left out); this pass replays ttf-parser's walk
+// (glyf.rs: parse_simple_outline — flag runs, short / same-or-positive coordinates, wrapping i16 sums — and Builder:
+// implied on-curve midpoints, the closing curve of a contour, close()) and writes the OutlineBuilder callbacks as the
+// OutlineCmd records every later pass reads: what csrc/host/ttf_face.cpp records on the host, callback for callback
+// (f32, one multiply-add pair per transformed coordinate, never fused).
+// A part owns `cmd_cap` >= points + 3 * contours command slots; the slots it does not need are filled with close():
+// on the empty ring that follows a contour's own close() the RingBuilder does nothing (ring_builder.rs:33-38).
+// error_flag bit 4: an entry whose arrays do not fit its bytes or its slots — ttf-parser would drop that glyph and, in a
+// composite, the components after it; the host records such a batch itself.
+// ---------------------------------------------------------------------------------------
+struct GlyfPart {          // mirrors vgsdf_glyf_part (include/vgsdf.h)
+	uint32_t byte_off;     // into `bytes`: endPtsOfContours[n_contours], then the flag / x / y arrays of the entry
+	uint32_t byte_len;
+	uint32_t cmd_at, cmd_cap;
+	uint32_t n_contours;
+	uint32_t plain;        // 1: identity transform
+	float a, b, c, d, e, f;
+};
+static_assert(sizeof(GlyfPart) == 48, "GlyfPart layout");
+
+// One wave per part, the points dealt out to the lanes (a lane that walks a 300-point glyph alone needs ~0.2 ms: ~700 dependent
+// instructions per point on a machine that issues one every few cycles per wave):
+//   A  flags: run-length decoding without a walk.  A byte of the flag stream is a repeat COUNT iff the byte in front of it
+//      is a flag with REPEAT set — inside a run of bytes that all carry bit 3 flags and counts alternate, so a byte's role
+//      follows from the length of the run of such bytes in front of it (one ballot per 64 bytes); runs are laid out by a
+//      prefix sum, every flag lands on the points it covers (LDS), the sizes of the x / y arrays come out as sums.
+//   B  coordinates: offset of a point's delta = prefix sum of the sizes its flags give, value = prefix sum of the deltas
+//      (mod 2^16, as the i16 additions of the walk wrap).
+//   C  contours and callbacks: the end points give every contour's first and last point (ttf-parser's EndpointsIter, also for
+//      end points that do not ascend); what Builder::push_point emits for a point depends on its own flag, the flag of
+//      the point in front of it and the first two points of its contour — no state is carried; the last point of a
+//      contour also emits what Builder::finish adds; positions by prefix sum.
+constexpr uint32_t kGlyfMaxPoints = 4096; // per part (LDS: 1 + 2 + 2 bytes per point); beyond: the host's reader (error_flag bit 4)
+
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v)
+{
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+		if ((int)(threadIdx.x & 63u) >= d)
+			v = max(v, o);
+	}
+	return v;
+}
+
+__global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ parts, uint32_t n_parts, const uint8_t *__restrict__ bytes,
+                                                  OutlineCmd *__restrict__ cmds, uint32_t *__restrict__ error_flag)
+{
+	__shared__ uint8_t s_flag[kGlyfMaxPoints];
+	__shared__ short s_x[kGlyfMaxPoints], s_y[kGlyfMaxPoints];
+	__shared__ uint32_t s_last[kGlyfMaxPoints / 32]; // bit p: point p is the last of its contour
+	if (blockIdx.x >= n_parts)
+		return;
+	const uint32_t lane = threadIdx.x;
+	const GlyfPart pt = parts[blockIdx.x];
+	const uint8_t *body = bytes + pt.byte_off;
+	const uint32_t len = pt.byte_len, nc = pt.n_contours, cap = pt.cmd_cap;
+	OutlineCmd *out = cmds + pt.cmd_at;
+	auto u16 = [&](uint32_t at) { return (uint32_t)((body[at] << 8) | body[at + 1]); };
+	auto close_cmd = [] {
+		OutlineCmd o;
+		o.x1 = o.y1 = o.x2 = o.y2 = o.x = o.y = 0.0f;
+		o.kind = CMD_CLOSE;
+		return o;
+	};
+	// everything below is wave-uniform control flow
+	bool ok = nc != 0 && 2u * nc <= len;
+	uint32_t n_points = 0;
+	if (ok) {
+		const uint32_t last_end = u16(2u * (nc - 1u));
+		ok = last_end != 0xFFFFu;
+		n_points = last_end + 1u;
+	}
+	uint32_t written = 0;
+	if (ok && n_points > 1u)
+		ok = n_points <= kGlyfMaxPoints && (unsigned long long)n_points + 3ull * nc <= cap;
+	if (ok && n_points > 1u) {
+		// ---- A: flags ----
+		uint32_t covered = 0, xs = 0, ys = 0, x_at = 2u * nc;
+		bool carry_count = false; // the first byte of the next 64 is a repeat count
+		for (uint32_t base = 2u * nc; covered < n_points && ok; base += 64u) {
+			const uint32_t j = base + lane;
+			const bool inb = j < len;
+			const uint32_t b = inb ? body[j] : 0u;
+			unsigned long long ones = __ballot(inb && (b & 0x08u));
+			if (carry_count)
+				ones &= ~1ull;
+			// role of byte j: the bytes [a, j) all carry bit 3 (a = the first such); flag, count, flag, ... from a on
+			const unsigned long long below = (1ull << lane) - 1ull;
+			const unsigned long long zeros_below = ~ones & below;
+			const uint32_t a = zeros_below ? 64u - (uint32_t)__builtin_clzll(zeros_below) : (carry_count ? 1u : 0u);
+			const bool is_count = lane == 0 ? carry_count : (((ones >> (lane - 1u)) & 1ull) != 0 && ((lane - 1u - a) & 1u) == 0);
+			const bool rep = ((ones >> lane) & 1ull) != 0 && !is_count;
+			// (the role of byte base + 64, computed the same way for a virtual lane 64)
+			{
+				const unsigned long long zb = ~ones;
+				const uint32_t a64 = zb ? 64u - (uint32_t)__builtin_clzll(zb) : (carry_count ? 1u : 0u);
+				carry_count = (ones >> 63) != 0 && ((63u - a64) & 1u) == 0;
+			}
+			const bool is_flag = inb && !is_count;
+			uint32_t run = 0;
+			bool bad = false;
+			if (is_flag) {
+				run = 1;
+				if (rep) {
+					if (j + 1u < len)
+						run += body[j + 1u];
+					else
+						bad = true; // the count lies behind the entry
+				}
+			}
+			uint32_t total_run;
+			const uint32_t start = covered + wave_exclusive_sum(run, total_run);
+			const bool needed = is_flag && start < n_points;
+			// the stream must not end before the points are covered, a run must not cross their end
+			const bool ends_here = !inb && start < n_points; // (a lane behind the entry while points are still open)
+			bad = (needed && (bad || start + run > n_points)) || ends_here;
+			if (__ballot(bad))
+				ok = false;
+			if (needed && !bad) {
+				for (uint32_t r = 0; r < run; r++)
+					s_flag[start + r] = (uint8_t)b;
+			}
+			const uint32_t cx = needed ? ((b & 0x02u) ? run : ((b & 0x10u) ? 0u : 2u * run)) : 0u;
+			const uint32_t cy = needed ? ((b & 0x04u) ? run : ((b & 0x20u) ? 0u : 2u * run)) : 0u;
+			uint32_t tx, ty;
+			(void)wave_exclusive_sum(cx, tx);
+			(void)wave_exclusive_sum(cy, ty);
+			xs += tx;
+			ys += ty;
+			const uint32_t end_here = needed ? j + 1u + (rep ? 1u : 0u) : 0u;
+			x_at = max(x_at, (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(end_here), 63));
+			covered += total_run; // (runs of bytes that are not needed any more do not matter: the loop ends)
+		}
+		const uint32_t y_at = x_at + xs, y_end = y_at + ys;
+		if (ok)
+			ok = y_end <= len;
+		if (ok) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			// ---- B: coordinates ----
+			uint32_t offx = x_at, offy = y_at;
+			int accx = 0, accy = 0;
+			for (uint32_t base = 0; base < n_points; base += 64u) {
+				const uint32_t p = base + lane;
+				const bool in = p < n_points;
+				const uint32_t fl = in ? s_flag[p] : 0x30u; // (0x30: no bytes, no delta)
+				const uint32_t szx = (fl & 0x02u) ? 1u : ((fl & 0x10u) ? 0u : 2u);
+				const uint32_t szy = (fl & 0x04u) ? 1u : ((fl & 0x20u) ? 0u : 2u);
+				uint32_t tx, ty;
+				const uint32_t ax = offx + wave_exclusive_sum(in ? szx : 0u, tx);
+				const uint32_t ay = offy + wave_exclusive_sum(in ? szy : 0u, ty);
+				offx += tx;
+				offy += ty;
+				int dx = 0, dy = 0;
+				if (in) {
+					if (fl & 0x02u) {
+						const int v = body[ax];
+						dx = (fl & 0x10u) ? v : -v;
+					} else if (!(fl & 0x10u)) {
+						dx = (int)(short)u16(ax);
+					}
+					if (fl & 0x04u) {
+						const int v = body[ay];
+						dy = (fl & 0x20u) ? v : -v;
+					} else if (!(fl & 0x20u)) {
+						dy = (int)(short)u16(ay);
+					}
+				}
+				uint32_t sdx, sdy;
+				const uint32_t ex = wave_exclusive_sum((uint32_t)dx, sdx), ey = wave_exclusive_sum((uint32_t)dy, sdy);
+				if (in) {
+					s_x[p] = (short)(unsigned short)((uint32_t)accx + ex + (uint32_t)dx); // wrapping i16 sums
+					s_y[p] = (short)(unsigned short)((uint32_t)accy + ey + (uint32_t)dy);
+				}
+				accx = (int)((uint32_t)accx + sdx);
+				accy = (int)((uint32_t)accy + sdy);
+			}
+			// ---- C: contours ----
+			for (uint32_t w = lane; w < (n_points + 31u) / 32u; w += 64u)
+				s_last[w] = 0;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			uint32_t laid = 0; // points of the contours laid out so far
+			for (uint32_t base = 0; base < nc; base += 64u) {
+				const uint32_t k = base + lane;
+				uint32_t L = 0;
+				if (k < nc) {
+					const uint32_t end = u16(2u * k);
+					if (k == 0) {
+						L = end + 1u;
+					} else {
+						const uint32_t prev = u16(2u * (k - 1u));
+						L = end > prev ? end - prev : 1u; // (a span of 0 still takes one point: EndpointsIter)
+					}
+				}
+				uint32_t tl;
+				const uint32_t first = laid + wave_exclusive_sum(L, tl);
+				if (k < nc) {
+					const unsigned long long last = (unsigned long long)first + L - 1ull;
+					if (last < n_points)
+						atomicOr(&s_last[last >> 5], 1u << (last & 31u));
+				}
+				laid += tl; // (sums beyond 2^32 cannot occur: nc * 65536 < 2^32)
+			}
+			// points behind the last contour: every one of them ends a contour of its own
+			for (uint32_t p = laid + lane; p < n_points; p += 64u)
+				atomicOr(&s_last[p >> 5], 1u << (p & 31u));
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			auto is_last = [&](uint32_t p) { return ((s_last[p >> 5] >> (p & 31u)) & 1u) != 0; };
+			auto map = [&](float &x, float &y) {
+				if (!pt.plain) {
+					const float tx = x, ty = y;
+					x = pt.a * tx + pt.c * ty + pt.e;
+					y = pt.b * tx + pt.d * ty + pt.f;
+				}
+			};
+			uint32_t start_carry = 0; // first point of the contour the previous 64 points ended in
+			for (uint32_t base = 0; base < n_points; base += 64u) {
+				const uint32_t p = base + lane;
+				const bool in = p < n_points;
+				// first point of p's contour: behind the nearest earlier last point
+				const uint32_t mark = (in && p > 0 && is_last(p - 1u)) ? p : 0u;
+				const uint32_t cstart = max(start_carry, wave_inclusive_max(mark));
+				start_carry = (uint32_t)__builtin_amdgcn_readlane((int)cstart, 63);
+				// how many callbacks point p brings (its own, and Builder::finish behind the last point of a contour), then where
+				uint32_t i = 0, n = 0;
+				bool on = false, on0 = false, on1 = false, pending = false, last_pt = false, has_start = false, has_lead = false, pend = false;
+				if (in) {
+					i = p - cstart;
+					on = (s_flag[p] & 1u) != 0;
+					on0 = (s_flag[cstart] & 1u) != 0;
+					on1 = i >= 1u && (s_flag[cstart + 1u] & 1u) != 0;
+					pending = i >= 1u && (s_flag[p - 1u] & 1u) == 0; // (read for i >= 2, or i == 1 behind an on-curve start)
+					const bool own = i == 0u ? on0 : ((i == 1u && !on0) ? true : (pending || on));
+					last_pt = is_last(p);
+					has_start = on0 || i >= 1u;
+					has_lead = !on0;
+					pend = i == 0u ? false : ((i == 1u && !on0) ? !on1 : !on);
+					n = (own ? 1u : 0u) + (last_pt ? ((has_lead && pend) ? 1u : 0u) + (has_start ? 1u : 0u) + 1u : 0u);
+				}
+				uint32_t tn;
+				uint32_t at = written + wave_exclusive_sum(n, tn);
+				auto emit = [&](uint32_t kind, float x1, float y1, float x, float y) {
+					if (at < cap) {
+						OutlineCmd o;
+						o.x1 = x1, o.y1 = y1, o.x2 = 0.0f, o.y2 = 0.0f, o.x = x, o.y = y;
+						o.kind = kind;
+						out[at] = o;
+					}
+					at++;
+				};
+				auto move = [&](float mx, float my) {
+					map(mx, my);
+					emit(CMD_MOVE, 0.0f, 0.0f, mx, my);
+				};
+				auto line = [&](float mx, float my) {
+					map(mx, my);
+					emit(CMD_LINE, 0.0f, 0.0f, mx, my);
+				};
+				auto quad = [&](float cx, float cy, float ex, float ey) {
+					map(cx, cy);
+					map(ex, ey);
+					emit(CMD_QUAD, cx, cy, ex, ey);
+				};
+				if (in && n) {
+					const float fx = (float)s_x[p], fy = (float)s_y[p];
+					const float x0 = (float)s_x[cstart], y0 = (float)s_y[cstart];
+					float x1 = 0, y1 = 0;
+					if (i >= 1u)
+						x1 = (float)s_x[cstart + 1u], y1 = (float)s_y[cstart + 1u];
+					// the contour's start point: its first point when that lies on the curve, else the second, else their middle
+					const float stx = on0 ? x0 : (on1 ? x1 : x0 + 0.5f * (x1 - x0));
+					const float sty = on0 ? y0 : (on1 ? y1 : y0 + 0.5f * (y1 - y0));
+					// Builder::push_point
+					if (i == 0u) {
+						if (on0)
+							move(fx, fy);
+					} else if (i == 1u && !on0) {
+						move(stx, sty);
+					} else if (pending) {
+						const float qx = (float)s_x[p - 1u], qy = (float)s_y[p - 1u];
+						if (on)
+							quad(qx, qy, fx, fy);
+						else
+							quad(qx, qy, qx + 0.5f * (fx - qx), qy + 0.5f * (fy - qy));
+					} else if (on) {
+						line(fx, fy);
+					}
+					if (last_pt) { // Builder::finish
+						if (has_lead && pend) {
+							quad(fx, fy, fx + 0.5f * (x0 - fx), fy + 0.5f * (y0 - fy));
+							pend = false;
+						}
+						if (has_start && has_lead)
+							quad(x0, y0, stx, sty);
+						else if (has_start && pend)
+							quad(fx, fy, stx, sty);
+						else if (has_start)
+							line(stx, sty);
+						emit(CMD_CLOSE, 0.0f, 0.0f, 0.0f, 0.0f);
+					}
+				}
+				written += tn;
+			}
+		}
+	}
+	if (!ok) {
+		if (lane == 0)
+			atomicOr(error_flag, 16u);
+		written = 0;
+	}
+	for (uint32_t k = written + lane; k < cap; k += 64u)
+		out[k] = close_cmd();
+}
+
 } // namespace vgsdf
 
 using namespace vgsdf;
+
+extern "C" int vgsdf_glyf_decode(const void *parts, uint32_t n_parts, const uint8_t *bytes, OutlineCmd *cmds, uint32_t *error_flag,
+                                 hipStream_t stream)
+{
+	if (n_parts == 0)
+		return 0;
+	hipLaunchKernelGGL(glyf_decode, dim3(n_parts), dim3(64), 0, stream, (const GlyfPart *)parts, n_parts, bytes, cmds, error_flag);
+	return (int)hipGetLastError();
+}
 
 extern "C" int vgsdf_outline_context(const OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
                                      uint8_t *cmd_open, uint32_t *error_flag, hipStream_t stream)

@@ -877,6 +877,12 @@ struct FeInput {
 	const uint32_t *pbf_pre = nullptr; // in-place PBF assembly (vgsdf_outlines_packed): both or neither
 	const uint8_t *pbf_fix = nullptr;
 	bool packed = false;
+	// vgsdf_outlines_glyf: the glyphs' `glyf` arrays instead of commands (cmd_off counts command SLOTS)
+	bool glyf = false;
+	const vgsdf_glyf_part *parts = nullptr;
+	uint32_t n_parts = 0;
+	const uint8_t *bytes = nullptr;
+	uint32_t n_bytes = 0;
 };
 
 static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_t spec_cap)
@@ -888,10 +894,11 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		ctx->err = "vgsdf_outlines: NULL argument";
 		return VGSDF_E_ARG;
 	}
-	if ((in->pbf_pre == nullptr) != (in->pbf_fix == nullptr) || (in->pbf_fix && !in->packed)) {
-		ctx->err = "vgsdf_outlines: pbf_pre and pbf_fix come together (packed form only)";
+	if ((in->pbf_pre == nullptr) != (in->pbf_fix == nullptr) || (in->pbf_fix && !in->packed && !in->glyf)) {
+		ctx->err = "vgsdf_outlines: pbf_pre and pbf_fix come together (packed and glyf forms only)";
 		return VGSDF_E_ARG;
 	}
+	static_assert(sizeof(vgsdf_glyf_part) == 48, "ABI struct mirrors the kernel struct");
 	static_assert(sizeof(vgsdf_outline_cmd) == sizeof(vgsdf::OutlineCmd), "ABI struct mirrors the kernel struct");
 	static_assert(sizeof(vgsdf_rect) == sizeof(vgsdf::OutlineRect), "ABI struct mirrors the kernel struct");
 	const uint32_t n = in->n_glyphs;
@@ -905,9 +912,31 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 			return VGSDF_E_ARG;
 		}
 	const uint32_t n_cmds = n ? in->cmd_off[n] : 0;
-	if (n_cmds && (in->packed ? !in->kinds : !in->cmds)) {
+	if (n_cmds && !in->glyf && (in->packed ? !in->kinds : !in->cmds)) {
 		ctx->err = "vgsdf_outlines: NULL command array";
 		return VGSDF_E_ARG;
+	}
+	if (in->glyf) {
+		// the parts tile the command slots in order, and their bytes lie inside `bytes` (what the bytes SAY is checked on
+		// the device, entry by entry)
+		if ((in->n_parts && (!in->parts || !in->bytes)) || (in->n_bytes & 3u)) {
+			ctx->err = "vgsdf_outlines_glyf: NULL parts / bytes, or n_bytes not a multiple of 4";
+			return VGSDF_E_ARG;
+		}
+		uint64_t slots = 0;
+		for (uint32_t i = 0; i < in->n_parts; i++) {
+			const vgsdf_glyf_part &pt = in->parts[i];
+			if (pt.cmd_at != slots || (pt.byte_off & 3u) || pt.byte_off > in->n_bytes || pt.byte_len > in->n_bytes - pt.byte_off ||
+			    pt.n_contours == 0) {
+				ctx->err = "vgsdf_outlines_glyf: parts must tile the command slots in order, with 4-aligned byte ranges inside `bytes`";
+				return VGSDF_E_ARG;
+			}
+			slots += pt.cmd_cap;
+		}
+		if (slots != n_cmds) {
+			ctx->err = "vgsdf_outlines_glyf: cmd_off[n_glyphs] differs from the parts' command slots";
+			return VGSDF_E_ARG;
+		}
 	}
 	uint32_t n_floats = 0;
 	if (in->packed && n) {
@@ -979,11 +1008,18 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	const size_t blob_pre = (blob_kinds + n_cmds + 3) & ~(size_t)3, blob_fix = blob_pre + 4 * (size_t)n;
 	const size_t blob_bytes = pbf ? blob_fix + n : blob_kinds + n_cmds;
 	const uint8_t *hb = (const uint8_t *)in->scale;
+	// glyf form in one block: scale | shift_x | cmd_off | (pad to 8) | parts | bytes | pbf_pre | pbf_fix
+	const size_t gl_parts = (meta_off + 4 * (size_t)(n + 1) + 7) & ~(size_t)7, gl_bytes = gl_parts + sizeof(vgsdf_glyf_part) * (size_t)in->n_parts;
+	const size_t gl_pre = gl_bytes + in->n_bytes, gl_fix = gl_pre + 4 * (size_t)n;
+	const size_t gl_total = in->pbf_fix ? gl_fix + n : gl_pre;
+	const bool gblob = in->glyf && (const uint8_t *)in->shift_x == hb + meta_shift && (const uint8_t *)in->cmd_off == hb + meta_off &&
+	                   (const uint8_t *)in->parts == hb + gl_parts && in->bytes == hb + gl_bytes &&
+	                   (!in->pbf_fix || ((const uint8_t *)in->pbf_pre == hb + gl_pre && in->pbf_fix == hb + gl_fix)) && is_pinned(hb, gl_total);
 	const bool blob = in->packed && (const uint8_t *)in->shift_x == hb + meta_shift && (const uint8_t *)in->cmd_off == hb + meta_off &&
 	                  (const uint8_t *)in->dat_off == hb + meta_dat && (const uint8_t *)in->coords == hb + blob_coords &&
 	                  in->kinds == hb + blob_kinds &&
 	                  (!pbf || ((const uint8_t *)in->pbf_pre == hb + blob_pre && in->pbf_fix == hb + blob_fix)) && is_pinned(hb, blob_bytes);
-	FE_TRY(fe.meta.ensure((blob ? blob_bytes : meta_bytes) + 16));
+	FE_TRY(fe.meta.ensure((blob ? blob_bytes : (in->glyf ? gl_total : meta_bytes)) + 16));
 	FE_TRY(fe.h_stage.ensure(meta_bytes + 16));
 	FE_TRY(fe.cmd_open.ensure((size_t)n_cmds + 1));
 	FE_TRY(fe.counts.ensure(4 * (size_t)(n_cmds + 1)));
@@ -1009,7 +1045,32 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		FE_TRY(hipEventRecord(ctx->ev0, st));
 	const uint8_t *d_kinds = nullptr;
 	const float *d_coords = nullptr;
-	if (blob) {
+	const uint8_t *d_parts = nullptr, *d_bytes = nullptr;
+	if (in->glyf) {
+		// (device layout = the single-block layout, whether the arrays arrive as one block or one by one)
+		uint8_t *dm = (uint8_t *)fe.meta.p;
+		if (gblob) {
+			FE_TRY(hipMemcpyAsync(dm, hb, gl_total, hipMemcpyHostToDevice, st));
+		} else {
+			FE_TRY(hipMemcpyAsync(dm + meta_scale, in->scale, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+			FE_TRY(hipMemcpyAsync(dm + meta_shift, in->shift_x, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+			FE_TRY(hipMemcpyAsync(dm + meta_off, in->cmd_off, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+			if (in->n_parts)
+				FE_TRY(hipMemcpyAsync(dm + gl_parts, in->parts, sizeof(vgsdf_glyf_part) * (size_t)in->n_parts, hipMemcpyHostToDevice, st));
+			if (in->n_bytes)
+				FE_TRY(hipMemcpyAsync(dm + gl_bytes, in->bytes, in->n_bytes, hipMemcpyHostToDevice, st));
+			if (pbf) {
+				FE_TRY(hipMemcpyAsync(dm + gl_pre, in->pbf_pre, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+				FE_TRY(hipMemcpyAsync(dm + gl_fix, in->pbf_fix, (size_t)n, hipMemcpyHostToDevice, st));
+			}
+		}
+		d_parts = dm + gl_parts;
+		d_bytes = dm + gl_bytes;
+		if (pbf) {
+			p.d_pbf_pre = (const uint32_t *)(dm + gl_pre);
+			p.d_pbf_fix = dm + gl_fix;
+		}
+	} else if (blob) {
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hb, blob_bytes, hipMemcpyHostToDevice, st));
 		d_coords = (const float *)((const uint8_t *)fe.meta.p + blob_coords);
 		d_kinds = (const uint8_t *)fe.meta.p + blob_kinds;
@@ -1029,7 +1090,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	} else if (n_cmds) {
 		FE_TRY(hipMemcpyAsync(fe.cmds.p, in->cmds, sizeof(vgsdf::OutlineCmd) * (size_t)n_cmds, hipMemcpyHostToDevice, st));
 	}
-	if (!blob) {
+	if (!blob && !in->glyf) {
 		uint8_t *hm = (uint8_t *)fe.h_stage.p;
 		std::memcpy(hm + meta_scale, in->scale, 8 * (size_t)n);
 		std::memcpy(hm + meta_shift, in->shift_x, 8 * (size_t)n);
@@ -1038,7 +1099,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 			std::memcpy(hm + meta_dat, in->dat_off, 4 * (size_t)(n + 1));
 		FE_TRY(hipMemcpyAsync(fe.meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
 	}
-	if (pbf && !blob) { // arrays that do not sit in the single-copy block: their own copies
+	if (pbf && !blob && !in->glyf) { // arrays that do not sit in the single-copy block: their own copies
 		FE_TRY(fe.pbf_in.ensure(5 * (size_t)n + 16));
 		FE_TRY(hipMemcpyAsync(fe.pbf_in.p, in->pbf_pre, 4 * (size_t)n, hipMemcpyHostToDevice, st));
 		FE_TRY(hipMemcpyAsync((uint8_t *)fe.pbf_in.p + 4 * (size_t)n, in->pbf_fix, (size_t)n, hipMemcpyHostToDevice, st));
@@ -1062,6 +1123,8 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		const size_t guess = fe.last_spans ? (size_t)fe.last_spans + fe.last_spans / 2 + 256 : fe.tile_cap;
 		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
+	if (in->glyf)
+		FE_KERNEL(vgsdf_glyf_decode(d_parts, in->n_parts, d_bytes, (vgsdf::OutlineCmd *)fe.cmds.p, (uint32_t *)fe.flag.p, st));
 	if (in->packed)
 		FE_KERNEL(vgsdf_outline_context_packed(d_kinds, d_coords,
 		                                       (const uint32_t *)((const uint8_t *)fe.meta.p + meta_dat), d.cmd_off, d.scale, n,
@@ -1139,6 +1202,11 @@ static int fe_wait(vgsdf_ctx *ctx, vgsdf_rect *rects_out, uint64_t *out_bytes, u
 	std::memcpy(rects_out, fe.h_rects.p, sizeof(vgsdf_rect) * (size_t)n);
 	vgsdf::PlanHeader hdr;
 	std::memcpy(&hdr, (const uint8_t *)fe.h_rects.p + p.hdr_off, sizeof hdr);
+	if (hdr.error & 16u) {
+		ctx->err = "vgsdf_outlines_glyf: a `glyf` entry whose arrays do not fit its bytes (ttf-parser drops such a glyph): record this batch "
+		           "with the host's reader";
+		return VGSDF_E_GLYF;
+	}
 	if (hdr.error & 2u) {
 		ctx->err = "vgsdf_outlines_prepare: unknown command kind";
 		return VGSDF_E_ARG;
@@ -1297,6 +1365,25 @@ int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in
 		f.pbf_pre = in->pbf_pre;
 		f.pbf_fix = in->pbf_fix;
 		f.packed = true;
+	}
+	return fe_submit(ctx, in ? &f : nullptr, out_bitmaps, out_bitmaps ? out_capacity : 0);
+}
+
+int vgsdf_outlines_submit_glyf(vgsdf_ctx *ctx, const vgsdf_outlines_glyf *in, uint8_t *out_bitmaps, size_t out_capacity)
+{
+	FeInput f;
+	if (in) {
+		f.n_glyphs = in->n_glyphs;
+		f.cmd_off = in->cmd_off;
+		f.scale = in->scale;
+		f.shift_x = in->shift_x;
+		f.pbf_pre = in->pbf_pre;
+		f.pbf_fix = in->pbf_fix;
+		f.glyf = true;
+		f.parts = in->parts;
+		f.n_parts = in->n_parts;
+		f.bytes = in->bytes;
+		f.n_bytes = in->n_bytes;
 	}
 	return fe_submit(ctx, in ? &f : nullptr, out_bitmaps, out_bitmaps ? out_capacity : 0);
 }

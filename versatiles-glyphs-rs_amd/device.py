@@ -43,11 +43,22 @@ class _COutlinesPacked(C.Structure):
                 ("pbf_pre", C.c_void_p), ("pbf_fix", C.c_void_p)]  # in-place PBF assembly: NULL = bitmaps packed back to back
 
 
+class _COutlinesGlyf(C.Structure):
+    _fields_ = [("n_glyphs", C.c_uint32), ("n_parts", C.c_uint32), ("n_bytes", C.c_uint32), ("cmd_off", C.c_void_p),
+                ("parts", C.c_void_p), ("bytes", C.c_void_p), ("scale", C.c_void_p), ("shift_x", C.c_void_p),
+                ("pbf_pre", C.c_void_p), ("pbf_fix", C.c_void_p)]
+
+
+# vgsdf_glyf_part: one simple glyph of a (possibly composite) glyph for the device's glyf decoder
+GLYF_PART_DTYPE = np.dtype([("byte_off", "<u4"), ("byte_len", "<u4"), ("cmd_at", "<u4"), ("cmd_cap", "<u4"), ("n_contours", "<u4"),
+                            ("plain", "<u4"), ("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("d", "<f4"), ("e", "<f4"), ("f", "<f4")])
+VGSDF_E_GLYF = -4
+
 VGSDF_SYMBOLS = [
     "vgsdf_device_count", "vgsdf_create", "vgsdf_destroy", "vgsdf_last_error", "vgsdf_render_batch",
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
-    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
+    "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_submit_glyf", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
     "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters", "vgsdf_outlines_pbf_positions", "vgsdf_outlines_peek",
 ]
 
@@ -91,6 +102,7 @@ def load_library():
         L.vgsdf_outlines_submit.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_wait.argtypes = [vp, vp, vp, vp, vp]
         L.vgsdf_outlines_submit_packed.argtypes = [vp, vp, vp, C.c_size_t]
+        L.vgsdf_outlines_submit_glyf.argtypes = [vp, vp, vp, C.c_size_t]
         L.vgsdf_outlines_segments.argtypes = [vp, vp, vp, vp, vp, vp]
         L.vgsdf_outlines_pbf_positions.argtypes = [vp, vp]
         L.vgsdf_outlines_peek.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -344,6 +356,32 @@ class SdfContext:
             keep["pbf_fix"] = np.ascontiguousarray(pbf_fix, dtype=np.uint8)
             co.pbf_fix = keep["pbf_fix"].ctypes.data
         rc = L.vgsdf_outlines_submit_packed(self._h, C.byref(co), host, capacity)
+        if rc != 0:
+            L.vgsdf_host_free(host)
+            self._check(rc)
+        self._inflight = (keep, host, capacity, n)
+
+    def outlines_submit_glyf(self, cmd_off, parts, glyf_bytes, scale, shift_x, capacity: int, pbf_pre=None, pbf_fix=None):
+        """outlines_submit for glyphs that arrive as their `glyf` arrays (vgsdf_outlines_glyf): the device decodes them"""
+        L = load_library()
+        keep = {
+            "cmd_off": np.ascontiguousarray(cmd_off, dtype=np.uint32), "parts": np.ascontiguousarray(parts, dtype=GLYF_PART_DTYPE),
+            "bytes": np.ascontiguousarray(glyf_bytes, dtype=np.uint8),
+            "scale": np.ascontiguousarray(scale, dtype=np.float64), "shift": np.ascontiguousarray(shift_x, dtype=np.float64),
+        }
+        n = len(keep["scale"])
+        host = L.vgsdf_host_alloc(max(capacity, 1))
+        if not host:
+            raise MemoryError("vgsdf_host_alloc")
+        co = _COutlinesGlyf(n, len(keep["parts"]), len(keep["bytes"]), keep["cmd_off"].ctypes.data, keep["parts"].ctypes.data,
+                            keep["bytes"].ctypes.data, keep["scale"].ctypes.data, keep["shift"].ctypes.data)
+        if pbf_pre is not None:
+            keep["pbf_pre"] = np.ascontiguousarray(pbf_pre, dtype=np.uint32)
+            co.pbf_pre = keep["pbf_pre"].ctypes.data
+        if pbf_fix is not None:
+            keep["pbf_fix"] = np.ascontiguousarray(pbf_fix, dtype=np.uint8)
+            co.pbf_fix = keep["pbf_fix"].ctypes.data
+        rc = L.vgsdf_outlines_submit_glyf(self._h, C.byref(co), host, capacity)
         if rc != 0:
             L.vgsdf_host_free(host)
             self._check(rc)

@@ -27,7 +27,7 @@ class PbfGlyph(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s", "total_s")] + \
-               [(k, C.c_uint64) for k in ("blocks", "glyphs", "rasters", "pixels", "segments", "pbf_bytes")]
+               [(k, C.c_uint64) for k in ("blocks", "glyphs", "rasters", "pixels", "segments", "pbf_bytes", "glyf_groups", "glyf_fallbacks")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -41,13 +41,14 @@ VGFONT_SYMBOLS = [
     "vg_name_to_id", "vg_manager_block_counts", "vg_manager_render_glyphs", "vg_manager_timings",
     "vg_manager_render_block", "vg_manager_render_blocks", "vg_render_glyph", "vg_manager_build_batch", "vg_glyph_batch_view",
     "vg_glyph_batch_free", "vg_manager_record_outlines", "vg_outline_batch_view", "vg_outline_batch_free", "vg_pbf_encode",
+    "vg_manager_record_glyf_parts", "vg_glyf_batch_view", "vg_glyf_batch_free",
     "vg_manager_scan", "vg_manager_font_ids", "vg_manager_font_file_names", "vg_parse_font_name", "vg_manager_generate_name",
     "vg_encode_codeblocks", "vg_manager_index_json", "vg_manager_families_json", "vg_writer_new_tar_path",
     "vg_writer_new_tar_fd", "vg_writer_new_dir", "vg_writer_write_file", "vg_writer_write_directory", "vg_writer_finish",
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
     "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
     "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_add_counters",
-    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf",
+    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device",
 ]
 
 _bound = False
@@ -70,6 +71,8 @@ def _L():
         L.vg_manager_set_device_front_end.restype = None
         L.vg_manager_set_in_place_pbf.argtypes = [vp, C.c_int]
         L.vg_manager_set_in_place_pbf.restype = None
+        L.vg_manager_set_glyf_on_device.argtypes = [vp, C.c_int]
+        L.vg_manager_set_glyf_on_device.restype = None
         L.vg_manager_add_font_with_name.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
         L.vg_manager_add_font_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
         L.vg_manager_add_path.argtypes = [vp, C.c_char_p]
@@ -274,6 +277,10 @@ class FontManager:
         """True (default): the raster stores bitmaps where the finished PBF has them; False: blocks are encoded afterwards"""
         _L().vg_manager_set_in_place_pbf(self._h, 1 if on else 0)
 
+    def set_glyf_on_device(self, on: bool):
+        """True (default): glyf fonts are decoded on the device; False: the host reader records the outline callbacks"""
+        _L().vg_manager_set_glyf_on_device(self._h, 1 if on else 0)
+
     def set_device_front_end(self, on: bool):
         """flatten / close / scale / bbox on the GPU instead of host threads (HIP renderer only)"""
         _L().vg_manager_set_device_front_end(self._h, 1 if on else 0)
@@ -437,6 +444,38 @@ class FontManager:
                     "advances": arr(C.cast(adv, C.c_void_p).value, n, np.uint32)}
         finally:
             _L().vg_outline_batch_free(h)
+
+    def record_glyf_parts(self, font_id: str) -> dict:
+        """the same for the device's glyf decoder: {cmd_off (command slots), parts, bytes, scale, shift_x, ids, advances}"""
+        from .device import GLYF_PART_DTYPE, _COutlinesGlyf
+        L = _L()
+        L.vg_manager_record_glyf_parts.restype = C.c_void_p
+        L.vg_manager_record_glyf_parts.argtypes = [C.c_void_p, C.c_char_p]
+        L.vg_glyf_batch_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vg_glyf_batch_free.argtypes = [C.c_void_p]
+        L.vg_glyf_batch_free.restype = None
+        h = L.vg_manager_record_glyf_parts(self._h, font_id.encode())
+        if not h:
+            raise RuntimeError(_err())
+        try:
+            co = _COutlinesGlyf()
+            ids, adv = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+            L.vg_glyf_batch_view(h, C.byref(co), C.byref(ids), C.byref(adv))
+            n = co.n_glyphs
+
+            def arr(ptr, count, dt):
+                if count == 0 or not ptr:
+                    return np.zeros(0, dtype=dt)
+                buf = (C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr)
+                return np.frombuffer(buf, dtype=dt, count=count).copy()
+
+            return {"cmd_off": arr(co.cmd_off, n + 1, np.uint32), "parts": arr(co.parts, co.n_parts, GLYF_PART_DTYPE),
+                    "bytes": arr(co.bytes, co.n_bytes, np.uint8),
+                    "scale": arr(co.scale, n, np.float64), "shift_x": arr(co.shift_x, n, np.float64),
+                    "ids": arr(C.cast(ids, C.c_void_p).value, n, np.uint32),
+                    "advances": arr(C.cast(adv, C.c_void_p).value, n, np.uint32)}
+        finally:
+            L.vg_glyf_batch_free(h)
 
     def build_batch(self, font_id: str) -> GlyphBatchHost:
         h = _L().vg_manager_build_batch(self._h, font_id.encode())
