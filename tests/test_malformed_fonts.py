@@ -44,6 +44,14 @@ if which == "product":
             continue
         rec = mgr.record_outlines(fid)
         assert len(rec["cmd_off"]) == len(rec["ids"]) + 1
+        try:   # the same glyphs for the device's decoder: nothing it lists lies outside its byte store
+            parts = mgr.record_glyf_parts(fid)
+        except RuntimeError:   # (the damage hit the table directory: a font without glyf outlines has no parts)
+            parts = None
+        if parts is not None:
+            assert list(parts["ids"]) == list(rec["ids"]) and len(parts["bytes"]) % 4 == 0
+            assert (parts["parts"]["byte_off"].astype("int64") + parts["parts"]["byte_len"] <= len(parts["bytes"])).all()
+            assert int(parts["cmd_off"][-1]) == int(parts["parts"]["cmd_cap"].sum())
         w = vg.DummyWriter()
         try:
             mgr.render_glyphs(w, r)
