@@ -55,8 +55,9 @@ struct GlyphDesc;
 extern "C" {
 // parts: vgsdf_glyf_part records (include/vgsdf.h); writes the commands of every part into its slots of `cmds`;
 // error_flag bit 4: a malformed entry
+// max_cmd_cap / max_byte_len: the largest cmd_cap / byte_len among the parts (they size the launch's LDS)
 int vgsdf_glyf_decode(const void *parts, uint32_t n_parts, const uint8_t *bytes, vgsdf::OutlineCmd *cmds, uint32_t *error_flag,
-                      hipStream_t stream);
+                      uint32_t max_cmd_cap, uint32_t max_byte_len, hipStream_t stream);
 // cmd_open: one byte per command (bit 0: ring open in front of it, bit 1: the glyph's scale is not positive finite)
 // error_flag: one zeroed word; bit 1 is raised for a command kind that is none of the five callbacks
 int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,

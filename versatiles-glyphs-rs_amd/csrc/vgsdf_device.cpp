@@ -916,6 +916,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		ctx->err = "vgsdf_outlines: NULL command array";
 		return VGSDF_E_ARG;
 	}
+	uint32_t glyf_max_cap = 0, glyf_max_len = 0;
 	if (in->glyf) {
 		// the parts tile the command slots in order, and their bytes lie inside `bytes` (what the bytes SAY is checked on
 		// the device, entry by entry)
@@ -926,6 +927,8 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		uint64_t slots = 0;
 		for (uint32_t i = 0; i < in->n_parts; i++) {
 			const vgsdf_glyf_part &pt = in->parts[i];
+			glyf_max_cap = std::max(glyf_max_cap, pt.cmd_cap);
+			glyf_max_len = std::max(glyf_max_len, pt.byte_len);
 			if (pt.cmd_at != slots || (pt.byte_off & 3u) || pt.byte_off > in->n_bytes || pt.byte_len > in->n_bytes - pt.byte_off ||
 			    pt.n_contours == 0) {
 				ctx->err = "vgsdf_outlines_glyf: parts must tile the command slots in order, with 4-aligned byte ranges inside `bytes`";
@@ -1124,7 +1127,8 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
 	if (in->glyf)
-		FE_KERNEL(vgsdf_glyf_decode(d_parts, in->n_parts, d_bytes, (vgsdf::OutlineCmd *)fe.cmds.p, (uint32_t *)fe.flag.p, st));
+		FE_KERNEL(vgsdf_glyf_decode(d_parts, in->n_parts, d_bytes, (vgsdf::OutlineCmd *)fe.cmds.p, (uint32_t *)fe.flag.p, glyf_max_cap,
+		                            glyf_max_len, st));
 	if (in->packed)
 		FE_KERNEL(vgsdf_outline_context_packed(d_kinds, d_coords,
 		                                       (const uint32_t *)((const uint8_t *)fe.meta.p + meta_dat), d.cmd_off, d.scale, n,
