@@ -957,6 +957,10 @@ __device__ __forceinline__ unsigned long long pbf_place(const OutlineRect &r, ui
 	return (unsigned long long)pre + ent_hdr + msg;
 }
 
+// KEEP: glyphs per thread whose rects (and classification) stay in registers for all three passes; PBF: in-place placement
+// is part of the unrolled passes (instances: <8, false> for packed bitmaps, <4, true> for in-place batches of <= 4096 glyphs;
+// eight inlined placements spill the 1024-thread workgroup to scratch: 21 -> 26 us)
+template <uint32_t KEEP, bool PBF>
 __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *__restrict__ rects, uint32_t n_glyphs, int span_list,
                                                              uint32_t delta_cap, uint32_t span_max, uint32_t span_budget,
                                                              uint32_t tile_cap, GlyphDesc *__restrict__ descs,
@@ -1005,10 +1009,8 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 	const uint32_t g_lo = min(tid * per, n_glyphs), g_hi = min(g_lo + per, n_glyphs);
 	// a run of up to eight glyphs (batches of <= 8192 glyphs: every group the dispatcher forms) stays in registers with its classification, so
 	// the rects are read once and classified once for both passes
-	constexpr uint32_t kKeep = 8;
-	// (in-place PBF assembly takes the re-reading loops: eight inlined placements in the unrolled ones spill the kernel —
-	// one 1024-thread workgroup, 128 VGPRs per lane — to scratch: 21 -> 26 us, against 13 us without the feature)
-	const bool kept = per <= kKeep && pbf_fix == nullptr;
+	constexpr uint32_t kKeep = KEEP;
+	const bool kept = per <= kKeep && (PBF || pbf_fix == nullptr);
 	OutlineRect kr[kKeep];
 	uint32_t kcls[kKeep], kT[kKeep], kn[kKeep], kw[kKeep];
 #pragma unroll
@@ -1038,12 +1040,18 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 		};
 		if (kept) {
 #pragma unroll
-			for (uint32_t j = 0; j < kKeep; j++)
+			for (uint32_t j = 0; j < kKeep; j++) {
 				if (kr[j].has_raster) { // (absent glyphs: zero rects)
 					my_s += kr[j].n_segments;
-					my_p += (unsigned long long)kr[j].w * kr[j].h;
+					if (!(PBF && pbf_fix != nullptr))
+						my_p += (unsigned long long)kr[j].w * kr[j].h;
 					bad |= (unsigned long long)kr[j].w * kr[j].h > 0xFFFFFFFFull - 256ull;
 				}
+				if (PBF && pbf_fix != nullptr && g_lo + j < g_hi) {
+					unsigned long long at;
+					my_p += pbf_place(kr[j], pbf_pre[g_lo + j], pbf_fix[g_lo + j], at);
+				}
+			}
 		} else {
 			for (uint32_t g = g_lo; g < g_hi; g++)
 				sum_one(g, rects[g]);
@@ -1084,7 +1092,7 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 #pragma unroll
 			for (uint32_t j = 0; j < kKeep; j++)
 				if (g_lo + j < g_hi)
-					desc_one(g_lo + j, kr[j], kcls[j], kn[j], kw[j], std::false_type{});
+					desc_one(g_lo + j, kr[j], kcls[j], kn[j], kw[j], std::integral_constant<bool, PBF>{});
 		} else {
 			for (uint32_t g = g_lo; g < g_hi; g++) {
 				const OutlineRect r = rects[g];
@@ -1694,7 +1702,11 @@ extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, i
                                   uint32_t launch_spans, const uint32_t *pbf_pre, const uint8_t *pbf_fix,
                                   unsigned long long *pbf_at, hipStream_t stream)
 {
-	hipLaunchKernelGGL(outline_plan, dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
+	if (pbf_fix != nullptr && n_glyphs <= 4u * kPlanThreads)
+		hipLaunchKernelGGL((outline_plan<4, true>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
+		                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at);
+	else
+	hipLaunchKernelGGL((outline_plan<8, false>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
 	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at);
 	return (int)hipGetLastError();
 }
