@@ -1108,35 +1108,51 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool all
 // G.out, laid out by outline_plan from pbf_pre / pbf_fix); what is left is the ~20 bytes around each bitmap and the
 // block headers, written here on the pool.  A block without a glyph of this group is encoded on its own (32 bytes).
 // Every position the device reports is checked against this side's own arithmetic.
-void FontManager::fe_assemble(const std::vector<Todo> &tasks, FeGroup &G)
+// What of the assembly needs no result of the device: the files of the blocks without a glyph of this group (211 of a
+// font's 256, typically: name + range only, ~35 bytes each, written into one store — a vector per file cost more than all
+// the header bytes of the font together) and the list of the others.  Runs on the calling thread between the submission and
+// the wait for the front-end's results, when it has nothing else to do.
+void FontManager::fe_prepare_pieces(const std::vector<Todo> &tasks, FeGroup &G)
 {
-	ThreadPool &tp = pool();
 	const double t3 = now_s();
 	const size_t nb = G.g1 - G.g0;
-	MergedOutlines &m = G.m;
 	using Piece = FeGroup::Piece;
 	std::vector<Piece> &piece = G.piece;
 	piece.assign(nb, Piece{});
-	// blocks without a glyph of this group (211 of a font's 256, typically): name + range only, ~35 bytes each, written
-	// into one store — a vector per file cost more than all the header bytes of the font together
 	size_t small_stride = 0;
 	for (size_t i = 0; i < nb; i++)
 		small_stride = std::max(small_stride, tasks[G.g0 + i].name->size() + 48);
 	std::vector<uint8_t> &small = G.small;
 	small.resize(nb * small_stride);
+	G.busy.clear();
+	for (size_t i = 0; i < nb; i++) {
+		if (G.task_g0[i] != G.task_g0[i + 1]) {
+			G.busy.push_back((uint32_t)i);
+			continue;
+		}
+		const Todo &td = tasks[G.g0 + i];
+		const std::string &range = td.block.range();
+		uint8_t *entries = small.data() + i * small_stride + kPbfHeadRoom + pbf_block_fields(td.name->size(), range.size());
+		uint8_t *file = write_pbf_block_header(entries, *td.name, range, 0);
+		piece[i] = Piece{file, (size_t)(entries - file)};
+	}
+	timings_.encode_s += now_s() - t3;
+}
+
+void FontManager::fe_assemble(const std::vector<Todo> &tasks, FeGroup &G)
+{
+	ThreadPool &tp = pool();
+	const double t3 = now_s();
+	MergedOutlines &m = G.m;
+	using Piece = FeGroup::Piece;
+	std::vector<Piece> &piece = G.piece;
 	std::atomic<uint64_t> n_raster{0}, n_pixels{0};
 	std::atomic<bool> mismatch{false};
 	uint8_t *arena = G.out.data();
-	tp.run(nb, [&](size_t i, unsigned) {
+	tp.run(G.busy.size(), [&](size_t bi, unsigned) {
+		const size_t i = G.busy[bi];
 		const Todo &td = tasks[G.g0 + i];
 		const uint32_t a = G.task_g0[i], b = G.task_g0[i + 1];
-		if (a == b) {
-			const std::string &range = td.block.range();
-			uint8_t *entries = small.data() + i * small_stride + kPbfHeadRoom + pbf_block_fields(td.name->size(), range.size());
-			uint8_t *file = write_pbf_block_header(entries, *td.name, range, 0);
-			piece[i] = Piece{file, (size_t)(entries - file)};
-			return;
-		}
 		uint64_t rasters = 0, pixels = 0;
 		uint8_t *first = nullptr, *end = nullptr;
 		for (uint32_t g = a; g < b; g++) {
@@ -1315,6 +1331,9 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		// in-place assembly: the rects come back right behind the plan kernel, a good 100 us before the bitmaps — the
 		// headers are written while the raster is still storing the bitmaps between them
 		bool early = false;
+		if (G.in_place && G.n_jobs)
+			fe_prepare_pieces(tasks, G);
+		t = now_s();
 		if (in_flight[k & 1] && G.in_place && G.n_jobs) {
 			early = renderer.peek_outlines((int)(k & 1), G.rects, G.out_bytes, G.n_jobs, &G.pbf_at);
 			timings_.device_s += now_s() - t;

@@ -288,6 +288,7 @@ private:
 		};
 		std::vector<Piece> piece;
 		std::vector<uint8_t> small; // blocks without a glyph of the group: name + range only
+		std::vector<uint32_t> busy; // the other blocks (indices into the group's tasks): assembled around their bitmaps
 		uint64_t n_raster = 0, n_pixels = 0;
 		HostBuffer<uint8_t> out{true};
 		uint64_t out_bytes = 0, n_segs = 0;
@@ -298,6 +299,7 @@ private:
 	void fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_layout_common(const std::vector<Todo> &tasks, FeGroup &G); // task_g0, pbf_pre of the merged batch
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
+	void fe_prepare_pieces(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_assemble(const std::vector<Todo> &tasks, FeGroup &G);
 	void fe_write_pieces(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
 	static bool glyf_on_device_default()
