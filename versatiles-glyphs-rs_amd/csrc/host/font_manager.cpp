@@ -938,6 +938,7 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 	const double t1 = now_s();
 	timings_.tessellate_s += t1 - t0;
 
+	static const bool trace_pack = std::getenv("VG_TRACE_PACK") != nullptr;
 	// merge in task order: jobs, command slots, parts and bytes of a slice are contiguous in its worker's batch
 	uint32_t n_jobs = 0, n_slots = 0, n_parts = 0, n_bytes = 0;
 	G.slice_cmd.resize(slices.size());
@@ -962,8 +963,10 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 	MergedOutlines &m = G.m;
 	m.jobs.resize(n_jobs);
 	G.in_place = in_place_pbf_;
+	const double tp0 = now_s();
 	m.layout_glyf(n_jobs, n_parts, n_bytes, G.in_place);
 	m.cmd_off[0] = 0;
+	const double tp1 = now_s();
 	tp.run(slices.size(), [&](size_t i, unsigned) {
 		const OSlice &s = slices[i];
 		const GlyfPartsBatch &l = workers_[s.worker].plocal;
@@ -991,7 +994,11 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 			m.cmd_off[g + 1] = G.slice_cmd[i] + (l.slot_off[j + 1] - s0);
 		}
 	});
+	const double tp2 = now_s();
 	fe_layout_common(tasks, G);
+	if (trace_pack)
+		std::fprintf(stderr, "[pack] slices %zu jobs %u parts %u bytes %u: sums %.1f us, layout %.1f, copy fork %.1f, common %.1f\n", slices.size(), n_jobs,
+		             n_parts, n_bytes, (tp0 - t1) * 1e6, (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (now_s() - tp2) * 1e6);
 	timings_.pack_s += now_s() - t1;
 }
 

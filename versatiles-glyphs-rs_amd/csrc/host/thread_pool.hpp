@@ -10,9 +10,10 @@
 //  * the join waits for the ITEMS, not for the workers: whoever is awake does the work, and the caller returns when
 //    the last item is done (rounds 1-2 waited until every worker had checked in, i.e. for the slowest of 15-31
 //    futex wake-ups, 50-90 us per fork when the workers had gone to sleep behind a device wait);
-//  * a few workers (max_spinners) poll the word for ~100 us after a fork before they sleep on the condition variable
-//    (the next fork usually follows within microseconds), the others sleep at once; the caller polls the count of
-//    finished items before it sleeps.
+//  * every worker polls the word for ~20 us after a fork (the forks of one phase sequence — record, merge — follow each
+//    other within microseconds: the merge of Noto Sans Regular takes 29 us with the workers still awake, 50-70 us when
+//    all but a few have to be woken), a few (max_spinners) keep polling for ~100 us before they sleep on the condition
+//    variable, the others sleep then; the caller polls the count of finished items before it sleeps.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -96,9 +97,18 @@ private:
 		}();
 		return us;
 	}
-	template <class Ready> static bool poll(Ready ready)
+	static long short_us()
 	{
-		const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us());
+		static const long us = [] {
+			const char *e = std::getenv("VG_POOL_SPIN_ALL_US"); // (measurement switch)
+			return e ? std::max(0l, std::atol(e)) : 20l;
+		}();
+		return us;
+	}
+	template <class Ready> static bool poll(Ready ready) { return poll_for(ready, spin_us()); }
+	template <class Ready> static bool poll_for(Ready ready, long us)
+	{
+		const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(us);
 		for (;;) {
 			for (int i = 0; i < 64; i++) {
 				if (ready())
@@ -167,10 +177,14 @@ private:
 		uint32_t seen = 0;
 		for (;;) {
 			auto moved = [&] { return gen_of(state_.load(std::memory_order_acquire)) != seen; };
-			bool came = false;
-			if (spinners_.fetch_add(1, std::memory_order_relaxed) < max_spinners())
-				came = poll(moved);
-			spinners_.fetch_sub(1, std::memory_order_relaxed);
+			// every worker polls briefly (forks of one phase sequence follow each other within microseconds: record ->
+			// merge), a few keep polling for the next sequence
+			bool came = short_us() ? poll_for(moved, short_us()) : false;
+			if (!came) {
+				if (spinners_.fetch_add(1, std::memory_order_relaxed) < max_spinners())
+					came = poll(moved);
+				spinners_.fetch_sub(1, std::memory_order_relaxed);
+			}
 			if (!came) {
 				std::unique_lock<std::mutex> l(mu_);
 				sleepers_.fetch_add(1, std::memory_order_seq_cst);
