@@ -61,7 +61,9 @@ vg_renderer *vg_renderer_new(int mode, int device_ordinal);
  * a HIP renderer with one lane per entry of `devices` (own device contexts and streams each; an entry may repeat a
  * device).  vg_manager_render_glyphs / _to with such a renderer deal every font's glyphs to the lanes by estimated
  * cost (vg_manager_shard_glyphs' table), render each shard on its own host thread, and merge the partial PBFs of a
- * block in this process's memory — there is no exchange step.  Output bytes equal a single-device run's.  The run
+ * block in this process's memory — there is no exchange step.  A run over many fonts (16 non-empty (font, block)
+ * tasks per lane and more) deals out whole tasks instead (manager.rs:86-97's unit, by glyph count): every file comes
+ * from one lane and nothing is merged.  Output bytes equal a single-device run's either way.  The run
  * counters {blocks, glyphs, pixels} are summed over the lanes with vgsdf_reduce_counters (RCCL all-reduce when the
  * devices are distinct) and checked; vg_manager_reduced_counters returns them.  NULL + vg_last_error() on failure. */
 vg_renderer *vg_renderer_new_multi(const int *devices, int n);

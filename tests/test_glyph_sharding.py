@@ -228,7 +228,9 @@ def test_one_process_many_device_lanes(vg, devices):
     shards are rendered by N host threads on N sets of device contexts (here all on the one GPU of the box), the partial
     PBFs are merged in this process's memory, and the result carries the golden SHA-256 of every block of config 4
     (Noto Sans all languages) and of Fira — through the native tar sink too.  The lanes' run counters are summed by
-    vgsdf_reduce_counters (host sum here: lanes that share a device cannot form an RCCL communicator)."""
+    vgsdf_reduce_counters (host sum here: lanes that share a device cannot form an RCCL communicator).
+    With two lanes the 91 non-empty blocks of the two fonts are plenty (>= 16 per lane): the lanes take whole (font, block) tasks
+    and nothing is merged (render_tasks_multi); with eight they are not, and the fonts' glyphs are sharded."""
     import tarfile
     golden = json.loads((GOLDEN / "pbf_sha256.json").read_text())
     from conftest import FIRA

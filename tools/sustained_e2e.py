@@ -4,7 +4,7 @@ container's CPU controller did meanwhile (cpu.stat: nr_throttled / throttled_use
 milliseconds — shorter than one period of the CPU quota — so they cannot show whether a pool of 2 x quota threads that
 spin between fork/joins runs into the quota when the run is long.
 
-usage: sustained_e2e.py [seconds=3] [workload=21fonts|noto_regular|noto_all]   (VG_THREADS / VG_POOL_SPIN_US vary the pool)
+usage: sustained_e2e.py [seconds=3] [workload=21fonts|noto_regular|noto_all] [lanes=1]   (VG_THREADS / VG_POOL_SPIN_US vary the pool)
 """
 import sys
 import time
@@ -36,7 +36,8 @@ def main():
         mgr.add_font_with_name("Noto Sans Regular", [td / "Noto Sans" / "Noto Sans - Regular.ttf"])
     else:
         mgr.add_font_with_name("Noto Sans", sorted((td / "Noto Sans").glob("*.ttf"), key=lambda q: q.name))
-    r = vg.Renderer.new_precise(0)
+    lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # > 1: that many device lanes of the library on the one GPU
+    r = vg.Renderer.new_precise(0) if lanes == 1 else vg.Renderer.new_multi([0] * lanes)
     for _ in range(3):
         mgr.render_glyphs(None, r)
     glyphs = mgr.timings()["glyphs"]

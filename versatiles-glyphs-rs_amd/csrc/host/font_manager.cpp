@@ -779,6 +779,105 @@ struct CaptureWriter final : Writer {
 };
 } // namespace
 
+// Many fonts: the lanes take WHOLE (font, block) tasks — the reference's own unit (manager.rs:86-97) — dealt out by glyph
+// count, longest first; every file is rendered, assembled and captured by one lane, nothing is merged.  (One font's ~45
+// unequal non-empty blocks do not balance over 8 devices: render_glyphs_multi shards its glyphs instead.)
+void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
+{
+	const double t_start = now_s();
+	const uint32_t world = (uint32_t)renderer.n_devices();
+	std::vector<Todo> all;
+	std::vector<const std::string *> names;
+	for (const auto &[name, font] : fonts_) {
+		names.push_back(&name);
+		for (const GlyphBlock &b : font.blocks())
+			all.push_back(Todo{&name, b});
+	}
+	// longest processing time first on the blocks' glyph counts; empty blocks go round
+	std::vector<uint32_t> order(all.size());
+	for (size_t i = 0; i < all.size(); i++)
+		order[i] = (uint32_t)i;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return all[a].block.len() > all[b].block.len(); });
+	std::vector<uint64_t> load(world, 0);
+	std::vector<uint32_t> owner(all.size(), 0);
+	uint32_t rr = 0;
+	for (uint32_t i : order) {
+		uint32_t r;
+		if (all[i].block.is_empty()) {
+			r = rr++ % world;
+		} else {
+			r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+			load[r] += all[i].block.len();
+		}
+		owner[i] = r;
+	}
+	std::vector<std::vector<Todo>> lane_tasks(world);
+	std::vector<uint32_t> slot(all.size()); // position of task i among its lane's tasks
+	for (size_t i = 0; i < all.size(); i++) {
+		slot[i] = (uint32_t)lane_tasks[owner[i]].size();
+		lane_tasks[owner[i]].push_back(all[i]);
+	}
+	const double t_sharded = now_s();
+
+	renderer.reset_counters();
+	std::vector<CaptureWriter> parts(world);
+	std::vector<std::exception_ptr> errors(world);
+	std::vector<std::thread> threads;
+	for (uint32_t r = 0; r < world; r++)
+		threads.emplace_back([&, r] {
+			try {
+				children_[r]->run_tasks(lane_tasks[r], parts[r], renderer.device_lane(r));
+			} catch (...) {
+				errors[r] = std::current_exception();
+			}
+		});
+	for (std::thread &t : threads)
+		t.join();
+	for (const std::exception_ptr &e : errors)
+		if (e)
+			std::rethrow_exception(e); // first error aborts (manager.rs:117-121)
+	const double t_rendered = now_s();
+	for (uint32_t r = 0; r < world; r++)
+		if (parts[r].files.size() != lane_tasks[r].size())
+			throw std::runtime_error("render_glyphs: a device lane produced " + std::to_string(parts[r].files.size()) + " files instead of " +
+			                         std::to_string(lane_tasks[r].size()));
+	timings_ = RenderTimings{};
+	for (const std::string *name : names)
+		writer.write_directory(*name + "/");
+	std::string path;
+	for (size_t i = 0; i < all.size(); i++) {
+		const std::vector<uint8_t> &file = parts[owner[i]].files[slot[i]];
+		all[i].block.path_into(*all[i].name, path);
+		writer.write_bytes(path, file.data(), file.size());
+		timings_.pbf_bytes += file.size();
+	}
+	const double t_written = now_s();
+	uint64_t want[3] = {all.size(), 0, 0};
+	for (uint32_t r = 0; r < world; r++) {
+		const RenderTimings &ct = children_[r]->timings_;
+		renderer.device_lane(r).add_counters(lane_tasks[r].size(), ct.glyphs, ct.pixels);
+		want[1] += ct.glyphs;
+		want[2] += ct.pixels;
+		timings_.tessellate_s = std::max(timings_.tessellate_s, ct.tessellate_s);
+		timings_.pack_s = std::max(timings_.pack_s, ct.pack_s);
+		timings_.device_s = std::max(timings_.device_s, ct.device_s);
+		timings_.encode_s = std::max(timings_.encode_s, ct.encode_s);
+		timings_.glyphs += ct.glyphs;
+		timings_.rasters += ct.rasters;
+		timings_.pixels += ct.pixels;
+		timings_.segments += ct.segments;
+		timings_.glyf_groups += ct.glyf_groups;
+		timings_.glyf_fallbacks += ct.glyf_fallbacks;
+	}
+	renderer.reduce_counters(reduced_);
+	if (std::memcmp(reduced_, want, sizeof want) != 0)
+		throw std::runtime_error("render_glyphs: the reduced run counters differ from the lanes' own");
+	timings_.blocks = all.size();
+	timings_.pack_s += t_sharded - t_start;
+	timings_.write_s = t_written - t_rendered;
+	timings_.total_s = now_s() - t_start;
+}
+
 void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 {
 	const double t_start = now_s();
@@ -798,6 +897,19 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 		c->batch_blocks_ = batch_blocks_;
 		c->batch_blocks_set_ = batch_blocks_set_;
 		c->set_threads(per_lane);
+	}
+	// whole tasks per lane when there are plenty of them (16 non-empty blocks per lane and more: a directory of fonts);
+	// VG_LANE_TASKS=0 / 1 forces one form (measurement switch)
+	{
+		size_t busy = 0;
+		for (const auto &kv : fonts_)
+			for (const GlyphBlock &b : kv.second.blocks())
+				busy += !b.is_empty();
+		static const char *force = std::getenv("VG_LANE_TASKS");
+		if (force ? force[0] == '1' : busy >= 16u * world) {
+			render_tasks_multi(writer, renderer);
+			return;
+		}
 	}
 	// shard tables of every font, built on this manager's pool before the lanes start (they only read them)
 	for (const auto &[name, font] : fonts_)

@@ -258,6 +258,7 @@ private:
 	void invalidate_shards();
 	uint64_t reduced_[3] = {0, 0, 0};
 	void run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
+	void render_tasks_multi(Writer &writer, const Renderer &renderer); // N device lanes, whole (font, block) tasks each
 	void run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
 	// tessellate tasks [t0, t1) on the pool and pack them (task order, ascending id) into `out`
 	void tessellate_and_pack(const std::vector<Todo> &tasks, size_t t0, size_t t1, std::vector<Slice> &slices,
