@@ -143,13 +143,27 @@ def in_library(n):
         return best, tm
     b1, t1 = best_of(single)
     bn, tn = best_of(lanes)
+    # a directory of fonts (every fixture file a font of its own: the `recurse` case): plenty of (font, block) tasks, the lanes
+    # take whole tasks and nothing is merged
+    td = ROOT / "testdata"
+    mf = vg.FontManager(True)
+    for i, p in enumerate([td / "Fira Sans - Regular.ttf"] + sorted((td / "Noto Sans").glob("*.ttf"), key=lambda q: q.name)):
+        mf.add_font_with_name(f"Font {i:02d}", [p])
+    mm_keep, mm = mm, mf   # (best_of renders `mm`)
+    f1, ft1 = best_of(single)
+    fn, ftn = best_of(lanes)
+    many = {"fonts": 21, "glyphs": ftn["glyphs"], "seconds": fn, "glyphs_per_s": ftn["glyphs"] / fn, "one_device_seconds": f1,
+            "one_device_glyphs_per_s": ft1["glyphs"] / f1, "reduced_counters": list(mf.reduced_counters()),
+            "note": "the 21 fixture files as 21 fonts: whole (font, block) tasks per lane, no merge"}
+    mm = mm_keep
     print(json.dumps({
         "note": "fonts -> PBF bytes (PCIe inclusive, native NULL sink) of Noto Sans all languages by ONE process: "
                 "Renderer.new_multi deals the glyph shards to N device lanes (one host thread each), partial PBFs merge in "
                 "shared memory, counters reduced by vgsdf_reduce_counters (RCCL when the lanes sit on distinct devices)",
         "devices": n, "lanes_share_one_device": share, "seconds": bn, "glyphs_per_s": tn["glyphs"] / bn,
         "one_device_seconds": b1, "one_device_glyphs_per_s": t1["glyphs"] / b1, "reduced_counters": list(mm.reduced_counters()),
-        "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}), flush=True)
+        "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")},
+        "many_fonts": many}), flush=True)
     lanes.close()
     single.close()
 
