@@ -198,6 +198,7 @@ void FontManager::invalidate_shards()
 	shard_cache_.clear();
 	shard_blocks_.clear();
 	children_.clear();
+	lane_plan_ = LanePlan{};
 }
 
 bool FontManager::add_font_with_name(const std::string &name, const std::vector<std::string> &sources, std::string *err)
@@ -786,37 +787,44 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 {
 	const double t_start = now_s();
 	const uint32_t world = (uint32_t)renderer.n_devices();
-	std::vector<Todo> all;
-	std::vector<const std::string *> names;
-	for (const auto &[name, font] : fonts_) {
-		names.push_back(&name);
-		for (const GlyphBlock &b : font.blocks())
-			all.push_back(Todo{&name, b});
-	}
-	// longest processing time first on the blocks' glyph counts; empty blocks go round
-	std::vector<uint32_t> order(all.size());
-	for (size_t i = 0; i < all.size(); i++)
-		order[i] = (uint32_t)i;
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return all[a].block.len() > all[b].block.len(); });
-	std::vector<uint64_t> load(world, 0);
-	std::vector<uint32_t> owner(all.size(), 0);
-	uint32_t rr = 0;
-	for (uint32_t i : order) {
-		uint32_t r;
-		if (all[i].block.is_empty()) {
-			r = rr++ % world;
-		} else {
-			r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
-			load[r] += all[i].block.len();
+	if (lane_plan_.world != world) { // (a font set's plan is kept: the sort of its 256 blocks per font costs as much as a small run)
+		LanePlan plan;
+		plan.world = world;
+		for (const auto &[name, font] : fonts_) {
+			plan.names.push_back(&name);
+			for (const GlyphBlock &b : font.blocks())
+				plan.all.push_back(Todo{&name, b});
 		}
-		owner[i] = r;
+		// longest processing time first on the blocks' glyph counts; empty blocks go round
+		std::vector<uint32_t> order(plan.all.size());
+		for (size_t i = 0; i < plan.all.size(); i++)
+			order[i] = (uint32_t)i;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plan.all[a].block.len() > plan.all[b].block.len(); });
+		std::vector<uint64_t> load(world, 0);
+		plan.owner.assign(plan.all.size(), 0);
+		uint32_t rr = 0;
+		for (uint32_t i : order) {
+			uint32_t r;
+			if (plan.all[i].block.is_empty()) {
+				r = rr++ % world;
+			} else {
+				r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+				load[r] += plan.all[i].block.len();
+			}
+			plan.owner[i] = r;
+		}
+		plan.lane_tasks.resize(world);
+		plan.slot.resize(plan.all.size()); // position of task i among its lane's tasks
+		for (size_t i = 0; i < plan.all.size(); i++) {
+			plan.slot[i] = (uint32_t)plan.lane_tasks[plan.owner[i]].size();
+			plan.lane_tasks[plan.owner[i]].push_back(plan.all[i]);
+		}
+		lane_plan_ = std::move(plan);
 	}
-	std::vector<std::vector<Todo>> lane_tasks(world);
-	std::vector<uint32_t> slot(all.size()); // position of task i among its lane's tasks
-	for (size_t i = 0; i < all.size(); i++) {
-		slot[i] = (uint32_t)lane_tasks[owner[i]].size();
-		lane_tasks[owner[i]].push_back(all[i]);
-	}
+	std::vector<Todo> &all = lane_plan_.all;
+	const std::vector<const std::string *> &names = lane_plan_.names;
+	const std::vector<uint32_t> &owner = lane_plan_.owner, &slot = lane_plan_.slot;
+	std::vector<std::vector<Todo>> &lane_tasks = lane_plan_.lane_tasks;
 	const double t_sharded = now_s();
 
 	renderer.reset_counters();

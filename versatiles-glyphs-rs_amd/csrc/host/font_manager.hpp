@@ -246,6 +246,15 @@ private:
 	FontManager(const FontManager *parent, uint32_t rank, uint32_t world);
 	const FontManager *parent_ = nullptr;
 	std::vector<std::unique_ptr<FontManager>> children_; // lanes, kept between runs (their buffers are grow-only)
+	// render_tasks_multi: which lane takes which (font, block) task; kept until a font is added (invalidate_shards)
+	struct LanePlan {
+		uint32_t world = 0;
+		std::vector<Todo> all;
+		std::vector<const std::string *> names;
+		std::vector<uint32_t> owner, slot;
+		std::vector<std::vector<Todo>> lane_tasks;
+	};
+	LanePlan lane_plan_;
 	// shard tables, built once per (font, world, number of files) — on the pool — and shared with the lanes
 	struct ShardEntry {
 		uint32_t world = 0;
