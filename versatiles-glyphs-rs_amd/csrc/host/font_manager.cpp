@@ -1054,7 +1054,7 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 			if (const FontFileEntry *f = blk.glyphs[ci])
 				Renderer::record_parts(f->face(), blk.start_index + ci, w.plocal);
 		s.job1 = (uint32_t)w.plocal.jobs.size();
-	});
+	}, true);
 	const double t1 = now_s();
 	timings_.tessellate_s += t1 - t0;
 
@@ -1113,7 +1113,7 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 			}
 			m.cmd_off[g + 1] = G.slice_cmd[i] + (l.slot_off[j + 1] - s0);
 		}
-	});
+	}, true);
 	const double tp2 = now_s();
 	fe_layout_common(tasks, G);
 	if (trace_pack)
@@ -1313,7 +1313,7 @@ void FontManager::fe_assemble(const std::vector<Todo> &tasks, FeGroup &G)
 		piece[i] = Piece{file, (size_t)(end - file)};
 		n_raster += rasters;
 		n_pixels += pixels;
-	});
+	}, true);
 	if (mismatch)
 		throw std::runtime_error("in-place PBF assembly: the device's layout of the arena differs from the host's");
 	G.n_raster = n_raster;

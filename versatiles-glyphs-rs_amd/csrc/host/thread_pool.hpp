@@ -54,7 +54,9 @@ public:
 
 	// fn(item, worker) for item in [0, n), dynamically scheduled; returns when all are done;
 	// rethrows the first exception (first error aborts, like try_for_each).
-	void run(size_t n, const std::function<void(size_t, unsigned)> &fn)
+	// light: the whole fork is a few tens of microseconds of work — less than it takes a sleeping worker to wake up.  It is
+	// left to the caller and the workers that are polling right now (if there are any); nobody is woken for it.
+	void run(size_t n, const std::function<void(size_t, unsigned)> &fn, bool light = false)
 	{
 		if (n == 0)
 			return;
@@ -70,10 +72,19 @@ public:
 		// this fork or is seen here
 		state_.store(word(gen, (uint32_t)n, 0), std::memory_order_seq_cst);
 		if (sleepers_.load(std::memory_order_seq_cst) != 0) {
-			{
-				std::lock_guard<std::mutex> l(mu_); // (pairs with the sleepers' predicate check: no lost wake-up)
+			const bool few = light && light_forks();
+			// a light fork takes the workers that are polling right now; with none polling, two are woken — not all
+			if (!(few && spinners_.load(std::memory_order_seq_cst) >= 2)) {
+				{
+					std::lock_guard<std::mutex> l(mu_); // (pairs with the sleepers' predicate check: no lost wake-up)
+				}
+				if (few) {
+					cv_.notify_one();
+					cv_.notify_one();
+				} else {
+					cv_.notify_all();
+				}
 			}
-			cv_.notify_all();
 		}
 		work(0, gen);
 		const uint32_t total = (uint32_t)n;
@@ -96,6 +107,14 @@ private:
 			return e ? std::max(0l, std::atol(e)) : 100l;
 		}();
 		return us;
+	}
+	static bool light_forks()
+	{
+		static const bool on = [] {
+			const char *e = std::getenv("VG_POOL_LIGHT"); // (measurement switch)
+			return e && e[0] == '1';
+		}();
+		return on;
 	}
 	static long short_us()
 	{
