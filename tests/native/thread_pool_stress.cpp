@@ -14,7 +14,7 @@ int main() {
 	for (int r = 0; r < ROUNDS; r++) {
 		const size_t n = 1 + (r * 7919) % 300;
 		std::vector<int> hit(n, 0);
-		tp.run(n, [&](size_t i, unsigned w) { hit[i]++; acc[w] += (long)i; });
+		tp.run(n, [&](size_t i, unsigned w) { hit[i]++; acc[w] += (long)i; }, /*light=*/r % 3 == 1); // (VG_POOL_LIGHT=1: those wake two workers at most)
 		for (size_t i = 0; i < n; i++) { if (hit[i] != 1) { std::printf("item %zu run %d hit %d\n", i, r, hit[i]); return 1; } want += (long)i; }
 		if (r % 100 == 0) std::this_thread::sleep_for(std::chrono::microseconds(300)); // let the workers fall asleep
 	}

@@ -22,9 +22,11 @@ def test_thread_pool_stress(tmp_path, flags):
     assert built.returncode == 0, built.stderr
     import os
     # default policy (a few workers poll, the others sleep at once), nobody polls, everybody polls
-    for spinners in (None, "0", "999"):
+    for spinners in (None, "0", "999", "light"):
         env = dict(os.environ)
-        if spinners is not None:
+        if spinners == "light":   # every third fork is a light one: at most two sleeping workers are woken for it
+            env["VG_POOL_LIGHT"] = "1"
+        elif spinners is not None:
             env["VG_POOL_SPINNERS"] = spinners
         run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=240, env=env)
         assert run.returncode == 0 and run.stdout.startswith("OK") and "ThreadSanitizer" not in run.stderr, \
