@@ -1021,6 +1021,23 @@ void FontManager::render_blocks(Writer &writer, const Renderer &renderer, const 
 // Host half of the device front-end for tasks [G.g0, G.g1): look the glyphs up, record their outline
 // commands on the pool (64-code-point slices, worker-local buffers), merge in task order into the
 // group's page-locked arrays.
+// units of host work of a group: 64-code-point slices of its non-empty blocks, in task order
+void FontManager::fe_make_slices(const std::vector<Todo> &tasks, FeGroup &G, uint32_t per_slice)
+{
+	G.slices.clear();
+	G.slice_ci.clear();
+	for (size_t t = G.g0; t < G.g1; t++) {
+		if (tasks[t].block.is_empty())
+			continue;
+		for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += per_slice) {
+			OSlice s;
+			s.task = (uint32_t)t;
+			G.slices.push_back(s);
+			G.slice_ci.push_back(c);
+		}
+	}
+}
+
 // The group's glyphs for the device's glyf decoder (vgsdf_outlines_glyf): the workers look every glyph up and copy the
 // arrays of its simple glyphs as they stand — no point is decoded on the host (0.56 us of CPU per glyph with the
 // recorder below, ~0.1 here).  Same slices, same merge in task order as fe_record.
@@ -1030,18 +1047,7 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 	ThreadPool &tp = pool();
 	const double t0 = now_s();
 	std::vector<OSlice> &slices = G.slices;
-	slices.clear();
-	G.slice_ci.clear();
-	for (size_t t = G.g0; t < G.g1; t++) {
-		if (tasks[t].block.is_empty())
-			continue;
-		for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += kSlice) {
-			OSlice s;
-			s.task = (uint32_t)t;
-			slices.push_back(s);
-			G.slice_ci.push_back(c);
-		}
-	}
+	fe_make_slices(tasks, G, kSlice);
 	for (Worker &w : workers_)
 		w.plocal.clear();
 	tp.run(slices.size(), [&](size_t i, unsigned wid) {
@@ -1156,18 +1162,7 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool all
 	ThreadPool &tp = pool();
 	const double t0 = now_s();
 	std::vector<OSlice> &slices = G.slices;
-	slices.clear();
-	G.slice_ci.clear();
-	for (size_t t = G.g0; t < G.g1; t++) {
-		if (tasks[t].block.is_empty())
-			continue;
-		for (uint32_t c = 0; c < GLYPH_BLOCK_SIZE; c += kSlice) {
-			OSlice s;
-			s.task = (uint32_t)t;
-			slices.push_back(s);
-			G.slice_ci.push_back(c);
-		}
-	}
+	fe_make_slices(tasks, G, kSlice);
 	for (Worker &w : workers_)
 		w.olocal.clear();
 	tp.run(slices.size(), [&](size_t i, unsigned wid) {

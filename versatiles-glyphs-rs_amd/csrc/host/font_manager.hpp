@@ -307,6 +307,7 @@ private:
 	FeGroup fe_group_[2]; // two groups in flight: one on the GPU, one being recorded / encoded
 	void fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool allow_glyf = true);
 	void fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G);
+	void fe_make_slices(const std::vector<Todo> &tasks, FeGroup &G, uint32_t per_slice);
 	void fe_layout_common(const std::vector<Todo> &tasks, FeGroup &G); // task_g0, pbf_pre of the merged batch
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);
 	void fe_prepare_pieces(const std::vector<Todo> &tasks, FeGroup &G);
