@@ -23,10 +23,11 @@ t0 = time.perf_counter()
 for i in range(iters):
     r = lanes if i % 3 else single
     m.set_in_place_pbf(i % 5 != 4)
+    m.set_glyf_on_device(i % 7 != 6)   # (mostly the device's glyf decoder, now and then the host's reader)
     w = vg.DummyWriter()
     m.render_glyphs(w, r)
     got = hashlib.sha256(b"".join(w.files[k] for k in sorted(w.files))).hexdigest()
     assert got == want, f"iteration {i}: output differs"
     if r is lanes:
         assert m.reduced_counters()[1] == m.timings()["glyphs"]
-print(f"{iters} renders ({lanes_n} lanes / single device alternating, in-place assembly on and off): all equal, {time.perf_counter() - t0:.1f} s")
+print(f"{iters} renders ({lanes_n} lanes / single device alternating, in-place assembly and device glyf decoder on and off): all equal, {time.perf_counter() - t0:.1f} s")
