@@ -835,9 +835,14 @@ struct PartsSink {
 		cur += 2 + body.u16(cur); // instructions: not needed on the device
 		if (cur > body.size())
 			return false;
+		// (an entry longer than the device's decoder takes is not copied — one damaged `loca` entry could otherwise make every
+		// glyph that names it carry megabytes: without its arrays the part fails there and the batch goes to the host's reader)
+		constexpr size_t kMaxEntry = 32 * 1024;
+		const bool fits = (size_t)n_contours * 2 + (body.size() - cur) <= kMaxEntry;
+		const size_t ends = fits ? (size_t)n_contours * 2 : 0, arrays = fits ? body.size() - cur : 0;
 		GlyfPart p;
 		p.byte_off = (uint32_t)bytes.size(); // (a multiple of 4: padded below)
-		p.byte_len = (uint32_t)((size_t)n_contours * 2 + (body.size() - cur));
+		p.byte_len = (uint32_t)(ends + arrays);
 		p.cmd_at = slots;
 		p.cmd_cap = n_points + 3u * n_contours;
 		p.n_contours = n_contours;
@@ -845,8 +850,10 @@ struct PartsSink {
 		p.a = a, p.b = b, p.c = c, p.d = d, p.e = e, p.f = f;
 		const size_t at = bytes.size(), padded = ((size_t)p.byte_len + 3) & ~(size_t)3;
 		bytes.resize(at + padded); // (zero padding)
-		std::memcpy(bytes.data() + at, body.data(), (size_t)n_contours * 2);
-		std::memcpy(bytes.data() + at + (size_t)n_contours * 2, body.data() + cur, body.size() - cur);
+		if (fits) {
+			std::memcpy(bytes.data() + at, body.data(), ends);
+			std::memcpy(bytes.data() + at + ends, body.data() + cur, arrays);
+		}
 		slots += p.cmd_cap;
 		parts.push_back(p);
 		return true;
