@@ -212,7 +212,7 @@ int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in
  *                                 the instructions to the end of the entry); byte_off a multiple of 4
  *   a b c d e f                   the transform ttf-parser has accumulated for the component (x' = a x + c y + e,
  *                                 y' = b x + d y + f, in f32); plain = 1 for the identity (a simple glyph drawn as itself)
- *   cmd_at, cmd_cap               its command slots: cmd_cap >= points + 3 * contours of the entry (what its end points say);
+ *   cmd_at, cmd_cap               its command slots: cmd_cap >= points + 2 * contours of the entry (what its end points say);
  *                                 the parts tile [0, cmd_off[n_glyphs]) in order, glyph g owns [cmd_off[g], cmd_off[g + 1])
  * A glyph without outline has no part and no slots.  Slots a part does not need are filled with close() callbacks, which
  * do nothing on the empty ring behind a contour's own close().  An entry whose arrays do not fit its bytes or its slots

@@ -74,7 +74,7 @@ def _batch(rng, n_glyphs, big=False):
             wild[-1] = wild[-1] or w
             p = np.zeros((), dtype=GLYF_PART_DTYPE)
             p["byte_off"], p["byte_len"] = len(data), len(body)
-            p["cmd_at"], p["cmd_cap"] = slots, n + 3 * nc + int(rng.integers(0, 3))
+            p["cmd_at"], p["cmd_cap"] = slots, n + 2 * nc + int(rng.integers(0, 3))
             p["n_contours"] = nc
             if rng.random() < 0.5:
                 p["plain"], p["a"], p["d"] = 1, 1.0, 1.0

@@ -17,7 +17,7 @@ for pat in ("trace/**/*kernel_stats.csv", "trace/**/*memory_copy_stats.csv"):
 front = ("glyf_decode", "outline_context", "outline_count", "outline_rings", "outline_plan", "outline_emit_segments", "sdf_chunk_boxes")
 lines = [f"# rocprofv3 --kernel-trace --memory-copy-trace --stats — end-to-end run with the device front-end "
          f"(tools/e2e_time.py noto_regular fe), {tag}", "",
-         "Noto Sans Regular, 2973 rasterised glyphs per call — 3993 `glyf` parts in 128 k command slots with the device's glyf decoder "
+         "Noto Sans Regular, 2973 rasterised glyphs per call — 3993 `glyf` parts in 122-128 k command slots with the device's glyf decoder "
          "(99 k outline commands when the host records them); 8 calls (4 warm runs x 2 thread settings).", "",
          "| kernel / copy | calls | avg us |", "|---|---|---|"]
 total = 0.0

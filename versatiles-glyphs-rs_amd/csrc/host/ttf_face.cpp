@@ -844,7 +844,9 @@ struct PartsSink {
 		p.byte_off = (uint32_t)bytes.size(); // (a multiple of 4: padded below)
 		p.byte_len = (uint32_t)(ends + arrays);
 		p.cmd_at = slots;
-		p.cmd_cap = n_points + 3u * n_contours;
+		// callbacks of a contour of L points: at most one per point, at most two from Builder::finish (the closing curves of a
+		// contour that begins AND ends off the curve — whose first point then emitted nothing) and close(): L + 2 in every case
+		p.cmd_cap = n_points + 2u * n_contours;
 		p.n_contours = n_contours;
 		p.plain = plain ? 1u : 0u;
 		p.a = a, p.b = b, p.c = c, p.d = d, p.e = e, p.f = f;

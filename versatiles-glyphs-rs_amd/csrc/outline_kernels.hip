@@ -1304,7 +1304,10 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 // implied on-curve midpoints, the closing curve of a contour, close()) and writes the OutlineBuilder callbacks as the
 // OutlineCmd records every later pass reads: what csrc/host/ttf_face.cpp records on the host, callback for callback
 // (f32, one multiply-add pair per transformed coordinate, never fused).
-// A part owns `cmd_cap` >= points + 3 * contours command slots; the slots it does not need are filled with close():
+// A part owns `cmd_cap` >= points + 2 * contours command slots (a contour of L points brings at most L + 2 callbacks: one per
+// point, the closing line or curve, close(); the second closing curve of a contour that begins and ends off the curve comes
+// instead of its first point's callback; end points that do not ascend cannot add contours — the lengths EndpointsIter
+// hands out sum to at least the point count); the slots it does not need are filled with close():
 // on the empty ring that follows a contour's own close() the RingBuilder does nothing (ring_builder.rs:33-38).
 // error_flag bit 4: an entry whose arrays do not fit its bytes or its slots — ttf-parser would drop that glyph and, in a
 // composite, the components after it; the host records such a batch itself.
@@ -1391,7 +1394,7 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 	}
 	uint32_t written = 0;
 	if (ok && n_points > 1u)
-		ok = n_points <= max_points && (unsigned long long)n_points + 3ull * nc <= cap;
+		ok = n_points <= max_points && (unsigned long long)n_points + 2ull * nc <= cap;
 	if (ok && n_points > 1u) {
 		// ---- A: flags ----
 		uint32_t covered = 0, xs = 0, ys = 0, x_at = 2u * nc;
