@@ -78,6 +78,26 @@ int main(int argc, char **argv)
 	}
 	vg_writer_free(w);
 	vg_renderer_free(r);
+	/* what the device's glyf decoder would be handed for this font (vgsdf_outlines_submit_glyf): built on the host, no GPU */
+	{
+		vg_glyf_batch *gb = vg_manager_record_glyf_parts(m, "fira_sans_regular");
+		vgsdf_outlines_glyf v;
+		const uint32_t *ids = NULL;
+		uint32_t i, slots = 0;
+		if (!gb || vg_glyf_batch_view(gb, &v, &ids, NULL) != 0) {
+			fprintf(stderr, "parts: %s\n", vg_last_error());
+			return 1;
+		}
+		for (i = 0; i < v.n_parts; i++) {
+			if (v.parts[i].cmd_at != slots || v.parts[i].byte_off % 4 || v.parts[i].byte_off + v.parts[i].byte_len > v.n_bytes)
+				return 3;
+			slots += v.parts[i].cmd_cap;
+		}
+		if (v.n_glyphs < 1000 || v.n_parts < v.n_glyphs || slots != v.cmd_off[v.n_glyphs] || ids[0] != 13)
+			return 4;
+		printf("parts %u of %u glyphs, %u bytes\n", (unsigned)v.n_parts, (unsigned)v.n_glyphs, (unsigned)v.n_bytes);
+		vg_glyf_batch_free(gb);
+	}
 	vg_manager_free(m);
 	printf("devices %d\n", vgsdf_device_count());
 	return 0;
@@ -102,6 +122,7 @@ def test_headers_are_plain_c_and_the_library_links_from_c(vg, tmp_path):
     shutil.copy(FIRA, fonts / "Fira Sans - Regular.ttf")
     out = tmp_path / "out"
     p = subprocess.run([str(exe), str(fonts), str(out)], capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stderr
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "parts " in p.stdout
     assert (out / "index.json").exists() and (out / "font_families.json").exists()
     assert len(list((out / "fira_sans_regular").glob("*.pbf"))) == 256
