@@ -47,14 +47,33 @@ struct vgo_font {
 	size_t loca_count;
 };
 
+/* table directory of face 0: the file, or the first face of a font collection ('ttcf'); (size_t)-1 for another magic
+ * (ttf-parser RawFace::parse: 0x00010000, 'true', 'OTTO', 'ttcf') */
+static size_t face_dir(const uint8_t *d, size_t len)
+{
+	if (len < 4)
+		return (size_t)-1;
+	uint32_t m = be32(d);
+	if (m == 0x00010000u || m == 0x74727565u || m == 0x4F54544Fu)
+		return 0;
+	if (m != 0x74746366u || len < 16 || be32(d + 8) == 0)
+		return (size_t)-1;
+	size_t at = be32(d + 12);
+	if (at < 16 || !rd_ok(len, at, 4))
+		return (size_t)-1;
+	m = be32(d + at);
+	return (m == 0x00010000u || m == 0x74727565u || m == 0x4F54544Fu) ? at : (size_t)-1;
+}
+
 static span find_table(const uint8_t *d, size_t len, const char *tag)
 {
 	span s = {NULL, 0};
-	if (len < 12)
+	size_t dir = face_dir(d, len);
+	if (dir == (size_t)-1 || !rd_ok(len, dir, 12))
 		return s;
-	int n = be16(d + 4);
+	int n = be16(d + dir + 4);
 	for (int i = 0; i < n; i++) {
-		size_t r = 12 + (size_t)i * 16;
+		size_t r = dir + 12 + (size_t)i * 16;
 		if (!rd_ok(len, r, 16))
 			break;
 		if (memcmp(d + r, tag, 4) == 0) {

@@ -14,13 +14,35 @@ namespace vg {
 
 namespace {
 
+// start of the table directory of face 0 (ttf-parser RawFace::parse with index 0): the file itself, or — a font
+// collection, magic 'ttcf' — the first face the collection lists; npos for any other magic than 0x00010000 / 'true' / 'OTTO'
+size_t face_directory(Bytes file)
+{
+	constexpr size_t npos = (size_t)-1;
+	auto is_face = [](uint32_t m) { return m == 0x00010000u || m == 0x74727565u || m == 0x4F54544Fu; };
+	if (!file.has(0, 4))
+		return npos;
+	const uint32_t magic = file.u32(0);
+	if (is_face(magic))
+		return 0;
+	if (magic != 0x74746366u || !file.has(4, 8)) // 'ttcf', version, numFonts
+		return npos;
+	if (file.u32(8) == 0 || !file.has(12, 4))
+		return npos;
+	const size_t at = file.u32(12);
+	if (at < 16 || !file.has(at, 4) || !is_face(file.u32(at))) // (behind the header it was read from; a face is not a collection)
+		return npos;
+	return at;
+}
+
 Bytes find_table(Bytes file, const char tag[4])
 {
-	if (!file.has(0, 12))
+	const size_t dir = face_directory(file);
+	if (dir == (size_t)-1 || !file.has(dir, 12))
 		return {};
-	const uint16_t n = file.u16(4);
+	const uint16_t n = file.u16(dir + 4);
 	for (uint16_t i = 0; i < n; i++) {
-		const size_t rec = 12 + (size_t)i * 16;
+		const size_t rec = dir + 12 + (size_t)i * 16;
 		if (!file.has(rec, 16))
 			return {};
 		if (std::memcmp(file.data() + rec, tag, 4) == 0)
