@@ -829,21 +829,9 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 
 	renderer.reset_counters();
 	std::vector<CaptureWriter> parts(world);
-	std::vector<std::exception_ptr> errors(world);
-	std::vector<std::thread> threads;
-	for (uint32_t r = 0; r < world; r++)
-		threads.emplace_back([&, r] {
-			try {
-				children_[r]->run_tasks(lane_tasks[r], parts[r], renderer.device_lane(r));
-			} catch (...) {
-				errors[r] = std::current_exception();
-			}
-		});
-	for (std::thread &t : threads)
-		t.join();
-	for (const std::exception_ptr &e : errors)
-		if (e)
-			std::rethrow_exception(e); // first error aborts (manager.rs:117-121)
+	// one item per lane on this manager's pool: its workers carry the lanes (each lane forks on its own, smaller pool);
+	// creating a thread per lane and run cost as much as a lane's share of a small run.  First error aborts (manager.rs:117-121)
+	pool().run(world, [&](size_t r, unsigned) { children_[r]->run_tasks(lane_tasks[r], parts[r], renderer.device_lane((int)r)); });
 	const double t_rendered = now_s();
 	for (uint32_t r = 0; r < world; r++)
 		if (parts[r].files.size() != lane_tasks[r].size())
@@ -926,21 +914,8 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 
 	renderer.reset_counters();
 	std::vector<CaptureWriter> parts(world);
-	std::vector<std::exception_ptr> errors(world);
-	std::vector<std::thread> threads;
-	for (uint32_t r = 0; r < world; r++)
-		threads.emplace_back([&, r] {
-			try {
-				children_[r]->render_glyphs(parts[r], renderer.device_lane(r));
-			} catch (...) {
-				errors[r] = std::current_exception();
-			}
-		});
-	for (std::thread &t : threads)
-		t.join();
-	for (const std::exception_ptr &e : errors)
-		if (e)
-			std::rethrow_exception(e); // first error aborts (manager.rs:117-121)
+	// (the pool's workers carry the lanes: see render_tasks_multi; first error aborts, manager.rs:117-121)
+	tp.run(world, [&](size_t r, unsigned) { children_[r]->render_glyphs(parts[r], renderer.device_lane((int)r)); });
 	const double t_rendered = now_s();
 
 	// merge: block b of every lane holds a disjoint subset of the block's glyphs
