@@ -245,6 +245,14 @@ private:
 	// a lane of render_glyphs_multi: shares the parent's fonts, renders the glyphs rank `rank` of `world` owns
 	FontManager(const FontManager *parent, uint32_t rank, uint32_t world);
 	const FontManager *parent_ = nullptr;
+public:
+	struct CaptureFile { // a file a lane has produced: [at, at + len) of its capture store
+		size_t at = 0, len = 0;
+	};
+
+private:
+	std::vector<uint8_t> capture_store_;     // (a lane's files of the current run: render_glyphs_multi / render_tasks_multi)
+	std::vector<CaptureFile> capture_files_;
 	std::vector<std::unique_ptr<FontManager>> children_; // lanes, kept between runs (their buffers are grow-only)
 	// render_tasks_multi: which lane takes which (font, block) task; kept until a font is added (invalidate_shards)
 	struct LanePlan {
