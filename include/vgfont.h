@@ -61,9 +61,9 @@ vg_renderer *vg_renderer_new(int mode, int device_ordinal);
  * a HIP renderer with one lane per entry of `devices` (own device contexts and streams each; an entry may repeat a
  * device).  vg_manager_render_glyphs / _to with such a renderer deal every font's glyphs to the lanes by estimated
  * cost (vg_manager_shard_glyphs' table), render each shard on its own host thread, and merge the partial PBFs of a
- * block in this process's memory — there is no exchange step.  A run over many fonts (16 non-empty (font, block)
- * tasks per lane and more) deals out whole tasks instead (manager.rs:86-97's unit, by glyph count): every file comes
- * from one lane and nothing is merged.  Output bytes equal a single-device run's either way.  The run
+ * block in this process's memory — there is no exchange step.  With at least four non-empty (font, block) tasks per
+ * lane (or when vg_manager_set_lane_form says so) whole tasks are dealt out instead (manager.rs:86-97's unit, by
+ * glyph count): every file comes from one lane and nothing is merged.  Output bytes equal a single-device run's either way.  The run
  * counters {blocks, glyphs, pixels} are summed over the lanes with vgsdf_reduce_counters (RCCL all-reduce when the
  * devices are distinct) and checked; vg_manager_reduced_counters returns them.  NULL + vg_last_error() on failure. */
 vg_renderer *vg_renderer_new_multi(const int *devices, int n);
@@ -89,6 +89,10 @@ void vg_manager_set_in_place_pbf(vg_manager *m, int on);
  * 0 = the host's reader records the callbacks (CFF / CFF2 fonts always take that way; so does a batch in which the device
  * finds a malformed entry).  Same bytes either way. */
 void vg_manager_set_glyf_on_device(vg_manager *m, int on);
+/* How a renderer of several device lanes (vg_renderer_new_multi) splits a run: -1 (default) whole (font, block) tasks per lane —
+ * manager.rs:86-97's unit — unless there are fewer than four non-empty blocks per lane, 0 always glyph-level shards of every
+ * font (merged afterwards), 1 always whole tasks.  Same bytes. */
+void vg_manager_set_lane_form(vg_manager *m, int form);
 int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
 int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
 /* manager.rs:39-53: the file's name table decides the font id (family/width/weight/style ->

@@ -222,21 +222,23 @@ def test_shard_arguments_and_stale_tables(vg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", [0, 1, -1])
 @pytest.mark.parametrize("devices", [[0, 0], [0] * 8])
-def test_one_process_many_device_lanes(vg, devices):
+def test_one_process_many_device_lanes(vg, devices, form):
     """SURVEY §8e / VERDICT r2 item 2: ONE process, N device lanes behind the C ABI (vg_renderer_new_multi): the glyph
     shards are rendered by N host threads on N sets of device contexts (here all on the one GPU of the box), the partial
     PBFs are merged in this process's memory, and the result carries the golden SHA-256 of every block of config 4
     (Noto Sans all languages) and of Fira — through the native tar sink too.  The lanes' run counters are summed by
     vgsdf_reduce_counters (host sum here: lanes that share a device cannot form an RCCL communicator).
-    With two lanes the 91 non-empty blocks of the two fonts are plenty (>= 16 per lane): the lanes take whole (font, block) tasks
-    and nothing is merged (render_tasks_multi); with eight they are not, and the fonts' glyphs are sharded."""
+    form 0: the fonts' glyphs are sharded over the lanes and the partial PBFs merged; form 1: the lanes take whole (font,
+    block) tasks and nothing is merged (render_tasks_multi); -1: the library chooses (whole tasks here: 91 non-empty blocks)."""
     import tarfile
     golden = json.loads((GOLDEN / "pbf_sha256.json").read_text())
     from conftest import FIRA
     m = vg.FontManager(True)
     m.add_font_with_name("Fira Sans Regular", [FIRA])
     m.add_font_with_name("Noto Sans Regular", noto_files())
+    m.set_lane_form(form)
     multi = vg.Renderer.new_multi(devices)
     assert multi.n_devices == len(devices)
     w = vg.DummyWriter()

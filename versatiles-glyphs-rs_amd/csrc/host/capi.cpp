@@ -113,6 +113,7 @@ void vg_manager_free(vg_manager *m) { delete m; }
 void vg_manager_set_device_front_end(vg_manager *m, int on) { m->m.set_device_front_end(on != 0); }
 void vg_manager_set_in_place_pbf(vg_manager *m, int on) { m->m.set_in_place_pbf(on != 0); }
 void vg_manager_set_glyf_on_device(vg_manager *m, int on) { m->m.set_glyf_on_device(on != 0); }
+void vg_manager_set_lane_form(vg_manager *m, int form) { m->m.set_lane_form(form < 0 ? -1 : (form ? 1 : 0)); }
 void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch)
 {
 	m->m.set_threads(threads);

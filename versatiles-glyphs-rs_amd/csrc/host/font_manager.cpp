@@ -912,15 +912,16 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 		c->batch_blocks_set_ = batch_blocks_set_;
 		c->set_threads(per_lane);
 	}
-	// whole tasks per lane when there are plenty of them (16 non-empty blocks per lane and more: a directory of fonts);
-	// VG_LANE_TASKS=0 / 1 forces one form (measurement switch)
+	// whole tasks per lane unless there are too few of them to go round (fewer than 4 non-empty blocks per lane: a small
+	// font on many devices); set_lane_form / VG_LANE_TASKS=0 / 1 forces one form
 	{
 		size_t busy = 0;
 		for (const auto &kv : fonts_)
 			for (const GlyphBlock &b : kv.second.blocks())
 				busy += !b.is_empty();
 		static const char *force = std::getenv("VG_LANE_TASKS");
-		if (force ? force[0] == '1' : busy >= 16u * world) {
+		const int form = lane_form_ >= 0 ? lane_form_ : (force ? (force[0] == '1') : -1);
+		if (form >= 0 ? form == 1 : busy >= 4u * world) {
 			render_tasks_multi(writer, renderer);
 			return;
 		}

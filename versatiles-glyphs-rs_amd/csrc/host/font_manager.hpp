@@ -206,6 +206,9 @@ public:
 	// glyf fonts through the device front-end: true (default; VG_GLYF_ON_DEVICE=0 in the environment changes it) = the
 	// device decodes the glyphs' `glyf` arrays, false = the host's reader records the callbacks.  Same bytes either way.
 	void set_glyf_on_device(bool on) { glyf_on_device_ = on; }
+	// a renderer with several device lanes: -1 (default) = whole (font, block) tasks per lane unless there are fewer than four
+	// non-empty blocks per lane, 0 = always glyph-level shards of every font (+ merge), 1 = always whole tasks.  Same bytes.
+	void set_lane_form(int form) { lane_form_ = form; }
 	// every glyph of a font id in the form the device's glyf decoder takes (glyf fonts only; tests, inspection)
 	bool record_glyf_parts(const std::string &font_id, GlyfPartsBatch &out, std::string *err) const;
 
@@ -327,6 +330,7 @@ private:
 		return !(e && e[0] == '0');
 	}
 	bool in_place_pbf_ = true;
+	int lane_form_ = -1;
 	bool glyf_on_device_ = glyf_on_device_default(); // glyf fonts: the device decodes the glyphs' arrays (VG_GLYF_ON_DEVICE=0 / set_glyf_on_device(false): the host does)
 	bool device_front_end_ = true; // HIP renderer: flatten on the GPU unless switched off
 	std::map<std::string, FontWrapper> fonts_; // reference: HashMap (arbitrary order); sorted here

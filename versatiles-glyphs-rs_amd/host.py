@@ -48,7 +48,7 @@ VGFONT_SYMBOLS = [
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
     "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
     "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_add_counters",
-    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device",
+    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device", "vg_manager_set_lane_form",
 ]
 
 _bound = False
@@ -73,6 +73,8 @@ def _L():
         L.vg_manager_set_in_place_pbf.restype = None
         L.vg_manager_set_glyf_on_device.argtypes = [vp, C.c_int]
         L.vg_manager_set_glyf_on_device.restype = None
+        L.vg_manager_set_lane_form.argtypes = [vp, C.c_int]
+        L.vg_manager_set_lane_form.restype = None
         L.vg_manager_add_font_with_name.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
         L.vg_manager_add_font_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
         L.vg_manager_add_path.argtypes = [vp, C.c_char_p]
@@ -280,6 +282,10 @@ class FontManager:
     def set_glyf_on_device(self, on: bool):
         """True (default): glyf fonts are decoded on the device; False: the host reader records the outline callbacks"""
         _L().vg_manager_set_glyf_on_device(self._h, 1 if on else 0)
+
+    def set_lane_form(self, form: int):
+        """several device lanes: -1 automatic, 0 glyph-level shards + merge, 1 whole (font, block) tasks per lane"""
+        _L().vg_manager_set_lane_form(self._h, int(form))
 
     def set_device_front_end(self, on: bool):
         """flatten / close / scale / bbox on the GPU instead of host threads (HIP renderer only)"""
