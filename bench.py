@@ -158,8 +158,9 @@ def in_library(n):
     mm = mm_keep
     print(json.dumps({
         "note": "fonts -> PBF bytes (PCIe inclusive, native NULL sink) of Noto Sans all languages by ONE process: "
-                "Renderer.new_multi deals the glyph shards to N device lanes (one host thread each), partial PBFs merge in "
-                "shared memory, counters reduced by vgsdf_reduce_counters (RCCL when the lanes sit on distinct devices)",
+                "Renderer.new_multi deals whole (font, block) tasks to N device lanes (glyph shards + a merge of partial PBFs when "
+                "there are fewer than four non-empty blocks per lane), counters reduced by vgsdf_reduce_counters (RCCL when the "
+                "lanes sit on distinct devices)",
         "devices": n, "lanes_share_one_device": share, "seconds": bn, "glyphs_per_s": tn["glyphs"] / bn,
         "one_device_seconds": b1, "one_device_glyphs_per_s": t1["glyphs"] / b1, "reduced_counters": list(mm.reduced_counters()),
         "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")},
