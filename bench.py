@@ -549,7 +549,8 @@ def main():
                 best, tm = dt, m.timings()   # (the phases reported are those of the best run)
         assert tm["pbf_bytes"] == n_bytes, (tm["pbf_bytes"], n_bytes)
         return {"glyphs_per_s": tm["glyphs"] / best, "seconds": best, "pbf_files": n_files, "pbf_bytes": n_bytes,
-                "phases_s": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")}}
+                "phases_s": {k: tm[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")},
+                "glyf_decoded_on_device": bool(tm.get("glyf_groups", 0)), "glyf_fallbacks": tm.get("glyf_fallbacks", 0)}
 
     def cpu_stat():
         try:
