@@ -810,11 +810,38 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 			for (const GlyphBlock &b : font.blocks())
 				plan.all.push_back(Todo{&name, b});
 		}
-		// longest processing time first on the blocks' glyph counts; empty blocks go round
+		// Longest processing time first; empty blocks go round.  A block's weight: its glyphs' outline sizes (command slots
+		// of their glyf entries + a constant per glyph; 40 per glyph of a CFF font) — a cheap stand-in for the raster's
+		// w*h*N that correlates 0.87 with it: with the glyph COUNT as weight the estimated raster cost per lane is up to
+		// 1.6 / 2.5 x the mean for Noto Sans Regular / all files on 8 lanes, with this weight 1.3 / 1.5 (the estimate
+		// itself as weight: 1.1 / 1.4 — at 28 / 45 non-empty blocks the largest block sets the limit).  Computed on
+		// the pool, once per font set.
+		std::vector<uint64_t> weight(plan.all.size(), 0);
+		pool().run(plan.all.size(), [&](size_t i, unsigned) {
+			const GlyphBlock &blk = plan.all[i].block;
+			if (blk.is_empty())
+				return;
+			std::vector<GlyfPart> parts;
+			std::vector<uint8_t> bytes;
+			uint64_t w = 0;
+			for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+				if (const FontFileEntry *f = blk.glyphs[ci]) {
+					uint32_t slots = 32;
+					if (f->face().has_glyf_outlines()) {
+						slots = 0;
+						parts.clear();
+						bytes.clear();
+						if (const auto gid = f->face().glyph_index(blk.start_index + ci))
+							(void)f->face().glyph_parts(*gid, parts, bytes, slots);
+					}
+					w += 8 + slots;
+				}
+			weight[i] = w;
+		});
 		std::vector<uint32_t> order(plan.all.size());
 		for (size_t i = 0; i < plan.all.size(); i++)
 			order[i] = (uint32_t)i;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plan.all[a].block.len() > plan.all[b].block.len(); });
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
 		std::vector<uint64_t> load(world, 0);
 		plan.owner.assign(plan.all.size(), 0);
 		uint32_t rr = 0;
@@ -824,7 +851,7 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 				r = rr++ % world;
 			} else {
 				r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
-				load[r] += plan.all[i].block.len();
+				load[r] += weight[i];
 			}
 			plan.owner[i] = r;
 		}
