@@ -16,6 +16,11 @@ Regular, full codepoint set, 1xMI355X").  value = glyphs/s over all ranks.
                     FontManager.shard_glyphs; BASELINE.json configs[3]:
                     `--workload noto_all --sharded`): strong scaling, total work fixed.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (the driver's own command) starts the N ranks
+ITSELF, as a child `python -m torch.distributed.run ... bench.py <same arguments>`, before this process has imported torch
+or touched a GPU, relays the one JSON line and exits with the child's status (launch_ranks below); with fewer HIP devices
+than ranks the ranks share device 0 over gloo (a rehearsal, said in the line).
+
 Exactly K steps are timed (W untimed warm-up launches first); `steady` repeats the measurement over a region of at
 least --min-ms (default 50 ms) and is reported beside the headline, never as `value`.  With --gpus N > 1 the same
 line also carries config 4 (`sharded_noto_all`: ONE font's glyphs split over the ranks, strong scaling), config 5
@@ -143,6 +148,7 @@ def in_library(n):
         return best, tm
     b1, t1 = best_of(single)
     bn, tn = best_of(lanes)
+    lane_form = "library default"
     # a directory of fonts (every fixture file a font of its own: the `recurse` case): plenty of (font, block) tasks, the lanes
     # take whole tasks and nothing is merged
     td = ROOT / "testdata"
@@ -162,11 +168,108 @@ def in_library(n):
                 "there are fewer than four non-empty blocks per lane), counters reduced by vgsdf_reduce_counters (RCCL when the "
                 "lanes sit on distinct devices)",
         "devices": n, "lanes_share_one_device": share, "seconds": bn, "glyphs_per_s": tn["glyphs"] / bn,
+        "counters_reduced_by": lanes.reduce_path(), "lane_form": lane_form,
         "one_device_seconds": b1, "one_device_glyphs_per_s": t1["glyphs"] / b1, "reduced_counters": list(mm.reduced_counters()),
         "phases_s": {k: tn[k] for k in ("tessellate_s", "pack_s", "device_s", "encode_s", "write_s")},
         "many_fonts": many}), flush=True)
     lanes.close()
     single.close()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    for ln in reversed(lines):
+        try:
+            return json.loads(ln)
+        except ValueError:
+            continue
+    return None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` as the driver types it, N > 1, no launcher: this process never imports torch and never
+    touches a GPU — it starts the ranks as a child (`python -m torch.distributed.run --nproc-per-node N bench.py <argv>`),
+    relays their one JSON line and returns the child's status.  The reference is ONE process (manager.rs:81-125); the line's
+    `in_library` field is that form (one process, N device lanes), the ranks are the benchmark contract's form.
+    Second attempt with the collectives on gloo when the first produced no line; last resort N independent one-device
+    processes without a barrier (labelled: a number beats no number on the first multi-GPU lease)."""
+    import subprocess
+    me = str(Path(__file__).resolve())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # devices visible: counted in a child, so that this process stays clear of the HIP runtime
+    try:
+        cp = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        n_dev = int(cp.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        n_dev = n
+    notes = []
+    if n_dev < n and env.get("VG_SHARE_GPU") != "1":
+        notes.append(f"{n_dev} HIP device(s) for {n} ranks: the ranks share device 0 (VG_SHARE_GPU=1) and the collectives go over gloo — a "
+                     "rehearsal of the code path, not a scaling measurement")
+        env["VG_SHARE_GPU"] = "1"
+    if env.get("VG_SHARE_GPU") == "1":
+        env.setdefault("VG_DIST_BACKEND", "gloo")   # RCCL refuses two ranks on one device
+    attempts = [dict(env)]
+    if env.get("VG_DIST_BACKEND", "nccl") != "gloo":
+        attempts.append(dict(env, VG_DIST_BACKEND="gloo"))
+    for k, e in enumerate(attempts):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), me] + list(argv)
+        try:
+            cp = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, text=True, timeout=1500)   # (stderr passes through)
+            line, rc = _json_line(cp.stdout), cp.returncode
+        except subprocess.TimeoutExpired as ex:
+            line, rc = _json_line(ex.stdout.decode() if isinstance(ex.stdout, bytes) else (ex.stdout or "")), 124
+        if line is not None:
+            line["launcher"] = {"form": "bench.py started its own ranks: python -m torch.distributed.run --nproc-per-node "
+                                        f"{n} (no WORLD_SIZE in the environment)", "attempt": k + 1, "devices_visible": n_dev, "notes": notes}
+            print(json.dumps(line), flush=True)
+            return rc
+        notes.append(f"attempt {k + 1} ({e.get('VG_DIST_BACKEND', 'nccl')}) ended with status {rc} and no result line")
+        print(f"[bench] {notes[-1]}", file=sys.stderr, flush=True)
+    # last resort: one process per device, no rendezvous at all
+    procs = []
+    for r in range(n):
+        e = dict(env, HIP_VISIBLE_DEVICES=str(0 if env.get("VG_SHARE_GPU") == "1" else r))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VG_SHARE_GPU"):
+            e.pop(k, None)
+        a = [x for x in argv]
+        i = a.index("--gpus") if "--gpus" in a else -1
+        if i >= 0:
+            a[i + 1] = "1"
+        else:
+            a = [x if not x.startswith("--gpus=") else "--gpus=1" for x in a]
+        procs.append(subprocess.Popen([sys.executable, me] + a + ["--no-cpu-baseline", "--no-e2e", "--no-configs", "--no-two-in-flight"],
+                                      env=e, stdout=subprocess.PIPE, text=True))
+    lines = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out = ""
+        lines.append(_json_line(out or ""))
+    good = [ln for ln in lines if ln]
+    if not good:
+        print("[bench] no rank produced a result", file=sys.stderr, flush=True)
+        return 1
+    line = good[0]
+    line["value"] = sum(ln["value"] for ln in good)
+    line["mpixel_sdf_per_s"] = sum(ln["mpixel_sdf_per_s"] for ln in good)
+    line["ms_per_step"] = max(ln["ms_per_step"] for ln in good)
+    line["n_gpus"] = len(good)
+    line["launcher"] = {"form": "LAST RESORT: independent one-device processes, started together, no barrier and no collective; value = "
+                                "sum of the processes' own rates", "ranks_with_a_result": len(good), "ranks_asked": n, "notes": notes}
+    print(json.dumps(line), flush=True)
+    return 0 if len(good) == n else 1
 
 
 def main():
@@ -196,8 +299,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # (nothing has touched a GPU yet)
         args.gpus = world
 
     import torch
@@ -267,6 +370,25 @@ def main():
     ctx.set_variant(args.variant)
     db = ctx.upload(hb.batch)       # inputs resident in HBM from here on
     st = db.stats()
+    # what a step leaves out: making the batch resident (one H2D copy from page-locked staging + sdf_chunk_boxes, once
+    # per batch) and fetching the bitmaps (one D2H copy) — wall clock around the synchronous C-ABI calls, best of 5
+    prep = None
+    if world == 1:
+        up, down = [], []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            d_tmp = ctx.upload(hb.batch)
+            up.append(time.perf_counter() - t1)
+            d_tmp.launch()
+            ctx.sync()
+            t1 = time.perf_counter()
+            d_tmp.download()
+            down.append(time.perf_counter() - t1)
+            d_tmp.free()
+        prep = {"upload_ms": min(up) * 1e3, "download_ms": min(down) * 1e3, "total_ms": (min(up) + min(down)) * 1e3,
+                "note": "NOT part of a step: vgsdf_batch_upload (pack + one H2D copy + sdf_chunk_boxes, synchronous) and "
+                        "vgsdf_batch_download (one D2H copy of the bitmaps into pageable memory) of the same batch, wall clock, best of 5; "
+                        "the end-to-end figures (`e2e`) include all of it and the front-end"}
 
     def barrier():
         if dist is not None:
@@ -436,9 +558,11 @@ def main():
             "unit": "GB/s",
             "frac": alg_gbs / HBM_PEAK_GBS,
             "traffic": pmc["bytes_per_launch"] if pmc else None,
+            "traffic_source": "builder-run rocprofv3 PMC passes, replayed from profiles/traffic.json (same kernel sources)" if pmc else None,
             "kernel": ("sdf_tiles_span<0>: the only kernel of a step (bounded groups over spans of tiles)"
                        if args.variant == 0 else f"variant {args.variant}"),
             "kernel_ms_avg": kernel_s * 1e3,
+            "prep_ms": prep,
             "alg_bytes_per_launch": st["alg_bytes"],
             "note": "the path is VALU bound, not HBM bound (f32 bounds/filter per pixel x candidate segment, f64 only "
                     "where the byte is undecided); see `valu`",
@@ -451,6 +575,8 @@ def main():
             "brute_pairs_per_s": st["n_pairs"] / kernel_s,
             "model_cycles_per_inst": pmc.get("valu_model_cycles_per_inst") if pmc else None,
             "mix": pmc.get("valu_mix") if pmc else None,
+            "source": "builder-run profile, replayed: rocprofv3 PMC passes of an earlier run of this command on these kernel sources "
+                      "(profiles/traffic.json, keyed by the kernel sources' SHA-256) — not measured by this invocation",
             "note": "VALU issue roofline from the rocprofv3 PMC passes recorded in profiles/traffic.json, reported only "
                     "when that file was collected on the kernel sources of this build (else null): VALU instructions per "
                     "wave; busy_frac = sum over the kernel's dynamic instruction mix (SQ_INSTS_VALU_* classes) of the "
@@ -468,6 +594,21 @@ def main():
                            "the GPU to its sustained clocks; reported beside the headline, never as `value`)"},
     }
     out.update(multi)
+    if world > 1 and not args.sharded:
+        out["scaling_note"] = ("weak, replicas: every rank renders its own copy of the config-2 batch, no data-path collective; `value` = "
+                               "N x glyphs of one batch x steps / max-over-ranks time.  The strong-scaling figure of BASELINE.json "
+                               "configs[3] (ONE font over N devices) is `strong_scaling_config4` (one rank per GPU, resident raster of each "
+                               "rank's glyph shard) and `in_library` (ONE process, N device lanes, fonts -> PBF bytes)")
+        if "sharded_noto_all" in multi:
+            m4 = multi["sharded_noto_all"]
+            out["strong_scaling_config4"] = {k: m4[k] for k in ("glyphs_per_s", "mpixel_sdf_per_s", "ms_per_step", "steps",
+                                                                "glyphs_per_step_all_gpus", "estimated_cost_max_over_mean")}
+            out["strong_scaling_config4"]["scaling"] = "strong"
+        if isinstance(multi.get("in_library"), dict) and "glyphs_per_s" in multi["in_library"]:
+            il = multi["in_library"]
+            out["in_library_config4"] = {"glyphs_per_s": il["glyphs_per_s"], "one_device_glyphs_per_s": il["one_device_glyphs_per_s"],
+                                         "devices": il["devices"], "lanes_share_one_device": il["lanes_share_one_device"],
+                                         "counters_reduced_by": il.get("counters_reduced_by")}
     if shard_info:
         out["config"]["shard"] = shard_info
 
@@ -496,7 +637,12 @@ def main():
     # ---- CPU baseline: oracle raster on the same tessellated batch, host cores ---------
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = O.default_threads()
+        # thread counts tried: the CPU affinity of the process (what the box shows: 256 on the one-GPU boxes) and the CPUs the
+        # container's cgroup lets it use at once (16 there) — the faster one is reported, with the count it used
+        quota = cpu_quota()
+        counts = [O.default_threads()]
+        if quota and int(round(quota)) >= 1 and int(round(quota)) not in counts and not os.environ.get("VG_CPU_THREADS"):
+            counts.append(int(round(quota)))
         got = db.download()
         sample, n_sample = hb.batch, st["n_glyphs"]
         if synthetic:  # bounded sample: the first 256 outlines of this rank's range (~10 s of CPU work)
@@ -504,33 +650,36 @@ def main():
             n_sample = min(256, st["n_glyphs"])
             sample = S.make_batch(rank * (args.synthetic_outlines or SYNTHETIC_PER_RANK), n_sample)
             got = got[:sample.out_bytes]
-        best = None
-        for mode, label in ((O.PRECISE, "±8 px envelope filter"), (O.BRUTE, "all segments")):
-            if synthetic and mode == O.BRUTE:
-                continue
-            for _ in range(1 if synthetic else 3):
-                ref, secs = O.sdf_render_batch(sample, mode, cores)
-                if not (ref == got).all():
-                    out["parity"] = f"MISMATCH vs oracle ({label})"
-                if best is None or secs < best[0]:
-                    best = (secs, label, mode)
+        best, tried = None, []
+        for cores in counts:
+            for mode, label in ((O.PRECISE, "±8 px envelope filter"), (O.BRUTE, "all segments")):
+                if synthetic and mode == O.BRUTE:
+                    continue
+                for _ in range(1 if synthetic else 3):
+                    ref, secs = O.sdf_render_batch(sample, mode, cores)
+                    if not (ref == got).all():
+                        out["parity"] = f"MISMATCH vs oracle ({label})"
+                    tried.append({"threads": cores, "rule": label, "seconds": secs})
+                    if best is None or secs < best[0]:
+                        best = (secs, label, mode, cores)
         out.setdefault("parity", "bit-exact vs oracle on the compared sample")
         _, secs1 = O.sdf_render_batch(sample, best[2], 1)   # the reference has --single-thread (recurse.rs:51-53)
+        per_count = {str(c): n_sample / min(t["seconds"] for t in tried if t["threads"] == c) for c in counts}
         out["cpu_baseline"] = {
             "value": n_sample / best[0],
             "unit": "glyphs/s",
-            "cores": cores,
+            "cores": best[3],
             "kind": "port",
             "sample": f"{n_sample} glyphs of the {args.workload} batch, raster only, same tessellated segments, best of "
-                      f"3 passes; faster of the oracle's candidate rules: {best[1]}",
+                      f"3 passes per setting; faster of the oracle's candidate rules ({best[1]}) and of the thread counts tried",
             "seconds": best[0],
             "single_thread": {"value": n_sample / secs1, "seconds": secs1},
             "cpu_model": cpu_model(),
-            "cpu_quota": cpu_quota(),
-            "threads_note": f"threads = CPU affinity of this process ({len(os.sched_getaffinity(0))}), no cap "
-                            f"(VG_CPU_THREADS overrides); machine reports {os.cpu_count()} logical CPUs; cpu_quota = CPUs the "
-                            "container's cgroup lets all of them use at once (null: no quota) — the GPU path's host pool runs "
-                            "under the same quota",
+            "cpu_quota": quota,
+            "glyphs_per_s_by_threads": per_count,
+            "threads_note": f"thread counts tried: CPU affinity of this process ({len(os.sched_getaffinity(0))}) and the cgroup's CPU quota "
+                            f"({quota}); `cores` = the count of the faster run (VG_CPU_THREADS fixes one); machine reports "
+                            f"{os.cpu_count()} logical CPUs; the GPU path's host pool runs under the same quota",
         }
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
 
@@ -577,11 +726,16 @@ def main():
         from oracle import oracle as O
         fonts = [O.Font(p) for p in font_paths]
         best = None
-        for mode in (O.PRECISE, O.BRUTE):
-            secs, ctr = O.render_all(fonts, font_id, mode, O.default_threads())
-            if best is None or secs < best[0]:
-                best = (secs, ctr, "±8 px envelope filter" if mode == O.PRECISE else "all segments")
-        return {"glyphs_per_s": best[1]["glyphs"] / best[0], "seconds": best[0], "threads": O.default_threads(),
+        counts = [O.default_threads()]
+        q = cpu_quota()
+        if q and int(round(q)) >= 1 and int(round(q)) not in counts and not os.environ.get("VG_CPU_THREADS"):
+            counts.append(int(round(q)))
+        for th in counts:
+            for mode in (O.PRECISE, O.BRUTE):
+                secs, ctr = O.render_all(fonts, font_id, mode, th)
+                if best is None or secs < best[0]:
+                    best = (secs, ctr, "±8 px envelope filter" if mode == O.PRECISE else "all segments", th)
+        return {"glyphs_per_s": best[1]["glyphs"] / best[0], "seconds": best[0], "threads": best[3], "threads_tried": counts,
                 "candidate_rule": best[2]}
 
     r = None

@@ -65,11 +65,15 @@ vg_renderer *vg_renderer_new(int mode, int device_ordinal);
  * lane (or when vg_manager_set_lane_form says so) whole tasks are dealt out instead (manager.rs:86-97's unit, by
  * glyph count): every file comes from one lane and nothing is merged.  Output bytes equal a single-device run's either way.  The run
  * counters {blocks, glyphs, pixels} are summed over the lanes with vgsdf_reduce_counters (RCCL all-reduce when the
- * devices are distinct) and checked; vg_manager_reduced_counters returns them.  NULL + vg_last_error() on failure. */
+ * devices are distinct; the host's own sum, flagged in vg_renderer_reduce_path, if RCCL fails) and checked; vg_manager_reduced_counters returns them.  NULL + vg_last_error() on failure. */
 vg_renderer *vg_renderer_new_multi(const int *devices, int n);
 int vg_renderer_device_count(const vg_renderer *r);
 /* sum of the lanes' run counters as they stand (vgsdf_reduce_counters over the renderer's contexts) */
 int vg_renderer_reduce_counters(const vg_renderer *r, uint64_t counters[3]);
+/* how the last reduce (vg_renderer_reduce_counters, or the one at the end of a multi-lane vg_manager_render_glyphs) took
+ * its sum: vgsdf_reduce_path of lane 0 — "rccl", "host: contexts share a device", "host: RCCL fallback: <reason>" ...
+ * (valid until the next call on this thread) */
+const char *vg_renderer_reduce_path(const vg_renderer *r);
 void vg_renderer_add_counters(const vg_renderer *r, int lane, uint64_t blocks, uint64_t glyphs, uint64_t pixels);
 void vg_renderer_reset_counters(const vg_renderer *r);
 void vg_renderer_free(vg_renderer *r);

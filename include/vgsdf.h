@@ -257,18 +257,29 @@ int vgsdf_outlines_segments(vgsdf_ctx *ctx, uint32_t *seg_off, double *sx, doubl
  * are independent (renderer.rs:103 has no shared state), so results need no exchange and the only collective of the
  * path is the sum of the run counters {blocks, glyphs, pixels} over the contexts.
  *   vgsdf_add_counters    : the dispatcher credits a context with the work it rendered there
- *   vgsdf_reduce_counters : counters[3] = sum over ctxs[0..n).  Contexts on n DISTINCT devices: an RCCL all-reduce
+ *   vgsdf_reduce_counters : counters[3] = sum over ctxs[0..n).  n >= 2 contexts on DISTINCT devices: an RCCL all-reduce
  *                           (sum, 3 x u64) over a communicator of exactly those devices, on the contexts' streams; every
  *                           rank's result is checked against the others.  RCCL is loaded at first use (dlopen of
- *                           librccl.so.1: no link-time dependency, shared with a host that already mapped it); if it
- *                           cannot be loaded the call fails with VGSDF_E_HIP.  Contexts that share a device (n lanes
- *                           rehearsed on one GPU) cannot form a communicator and are summed on the host.
- * Replaces nothing in the reference (single process, rayon threads: src/font/manager.rs:81-125 counts nothing); it is
+ *                           librccl.so.1: no link-time dependency, shared with a host that already mapped it).  The
+ *                           payload is 24 bytes the host already holds, so a finished render is never lost to the
+ *                           collective: if RCCL cannot be loaded, cannot form the communicator or fails, the sum is taken
+ *                           on the host, a line goes to stderr and vgsdf_reduce_path() says so.  One context, and contexts
+ *                           that share a device (n lanes rehearsed on one GPU: RCCL refuses two ranks on one device), are
+ *                           summed on the host.
+ *   vgsdf_reduce_counters_rccl : the same through RCCL or not at all (n >= 1 distinct devices; VGSDF_E_HIP when the
+ *                           collective is unavailable or fails, VGSDF_E_ARG when two contexts share a device) — for
+ *                           callers and tests that want the failure instead of the fallback.
+ *   vgsdf_reduce_path     : how the last reduce whose FIRST context was `ctx` took its sum: "rccl", "host: one context",
+ *                           "host: contexts share a device" or "host: RCCL fallback: <reason>".
+ * The all-reduce over distinct devices has not run on hardware yet (rounds 1-4 had one-GPU boxes; a one-rank communicator
+ * has).  Replaces nothing in the reference (single process, rayon threads: src/font/manager.rs:81-125 counts nothing); it is
  * the north star's "RCCL only for the final block-count reduce".
  */
 void vgsdf_add_counters(vgsdf_ctx *ctx, uint64_t blocks, uint64_t glyphs, uint64_t pixels);
 void vgsdf_reset_counters(vgsdf_ctx *ctx);
 int vgsdf_reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3]);
+int vgsdf_reduce_counters_rccl(vgsdf_ctx **ctxs, int n, uint64_t counters[3]);
+const char *vgsdf_reduce_path(const vgsdf_ctx *ctx);
 
 /* Raw device pointer of the resident output bitmaps (for zero-copy consumers on the same
  * device, e.g. a torch tensor wrapping it); valid until vgsdf_batch_free. */

@@ -58,8 +58,13 @@ static size_t face_dir(const uint8_t *d, size_t len)
 		return 0;
 	if (m != 0x74746366u || len < 16 || be32(d + 8) == 0)
 		return (size_t)-1;
+	/* the crate reads all numFonts offsets (a truncated array: no face) and subtracts the end of the array from the
+	 * face's offset with checked_sub (a face inside header or array: no face) */
+	uint64_t n_fonts = be32(d + 8);
+	if (4 * n_fonts > len || !rd_ok(len, 12, (size_t)(4 * n_fonts)))
+		return (size_t)-1;
 	size_t at = be32(d + 12);
-	if (at < 16 || !rd_ok(len, at, 4))
+	if (at < 12 + 4 * n_fonts || !rd_ok(len, at, 4))
 		return (size_t)-1;
 	m = be32(d + at);
 	return (m == 0x00010000u || m == 0x74727565u || m == 0x4F54544Fu) ? at : (size_t)-1;

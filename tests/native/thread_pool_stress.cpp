@@ -22,6 +22,14 @@ int main() {
 	bool threw = false;
 	try { tp.run(100, [&](size_t i, unsigned) { if (i == 37) throw std::runtime_error("boom"); }); } catch (const std::exception &e) { threw = std::string(e.what()) == "boom"; }
 	tp.run(10, [&](size_t, unsigned) {});
+	// an exception that is not a std::exception is reported, not std::terminate on a pool thread (round-3 advice)
+	bool threw_other = false;
+	try { tp.run(100, [&](size_t i, unsigned) { if (i == 5) throw 42; }); } catch (const std::exception &e) { threw_other = std::string(e.what()).find("unknown") != std::string::npos; }
+	// run() from an item of a running fork is refused instead of overwriting the fork in flight
+	bool nested = false;
+	try { tp.run(4, [&](size_t, unsigned) { tp.run(2, [](size_t, unsigned) {}); }); } catch (const std::exception &e) { nested = std::string(e.what()).find("re-entrant") != std::string::npos; }
+	tp.run(10, [&](size_t, unsigned) {});
+	threw = threw && threw_other && nested;
 	std::printf("%s sum %ld want %ld threw %d\n", got == want ? "OK" : "BAD", got, want, threw);
 	return got == want && threw ? 0 : 1;
 }

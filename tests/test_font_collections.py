@@ -65,3 +65,42 @@ def test_unknown_magic_is_not_a_font(oracle, vg):
     empty[8:12] = (0).to_bytes(4, "big")
     with pytest.raises(RuntimeError):
         vg.FontManager(False).add_font_data("Empty", bytes(empty))
+
+
+def test_collection_offset_array_is_read_whole(oracle, vg):
+    """ttf-parser's RawFace::parse reads all numFonts offsets (out of bounds: no face) and requires the face behind the
+    array (`face_offset.checked_sub(s.offset())`); round-3 advice: this reader only looked at offsets[0]."""
+    ttc = bytearray(_collection([FIRA, NOTO]))
+    assert int.from_bytes(ttc[8:12], "big") == 2
+    # numFonts claims more offsets than the file holds
+    trunc = bytearray(ttc)
+    trunc[8:12] = (len(ttc) // 4 + 10).to_bytes(4, "big")
+    for bad in (trunc,):
+        with pytest.raises(RuntimeError):
+            vg.FontManager(False).add_font_data("Truncated", bytes(bad))
+        with pytest.raises(Exception):
+            oracle.Font(bytes(bad))
+    # a valid face placed INSIDE the offset array's extent: numFonts = 6 -> the array ends at 36; the face sits at 16
+    face = Path_read(FIRA)
+    inside = bytearray(b"ttcf" + (0x00010000).to_bytes(4, "big") + (6).to_bytes(4, "big") + (16).to_bytes(4, "big")) + bytearray(face)
+    # (tables of the embedded face are addressed from the start of the file: shift them)
+    n_tables = int.from_bytes(face[4:6], "big")
+    for i in range(n_tables):
+        rec = 16 + 12 + 16 * i
+        off = int.from_bytes(inside[rec + 8:rec + 12], "big") + 16
+        inside[rec + 8:rec + 12] = off.to_bytes(4, "big")
+    with pytest.raises(RuntimeError):
+        vg.FontManager(False).add_font_data("Inside", bytes(inside))
+    with pytest.raises(Exception):
+        oracle.Font(bytes(inside))
+    # the same bytes with numFonts = 1 (array ends at 16 = the face's offset) load: the shifted directory is sound
+    ok = bytearray(inside)
+    ok[8:12] = (1).to_bytes(4, "big")
+    fid, files, _ = _render(vg, "Some Font", bytes(ok))
+    assert len(files) == 256
+    assert oracle.Font(bytes(ok)) is not None
+
+
+def Path_read(p):
+    from pathlib import Path
+    return Path(p).read_bytes()

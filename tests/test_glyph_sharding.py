@@ -271,21 +271,54 @@ def test_one_process_many_device_lanes(vg, devices, form):
 
 @pytest.mark.gpu
 def test_reduce_counters_through_rccl(vg):
-    """vgsdf_reduce_counters on contexts of DISTINCT devices is an RCCL all-reduce (sum, 3 x u64) over a communicator of
-    those devices.  This box has one GPU: a communicator of one rank still loads RCCL, creates the communicator and runs
-    the collective on the context's stream; the two-lanes-on-one-device case is the host sum."""
+    """vgsdf_reduce_counters on >= 2 contexts of DISTINCT devices is an RCCL all-reduce (sum, 3 x u64) over a communicator
+    of those devices; one context and contexts that share a device are summed on the host.  This box has one GPU: the
+    strict form (vgsdf_reduce_counters_rccl) with a communicator of one rank still loads RCCL, creates the communicator
+    and runs the collective on the context's stream."""
     a, b = vg.SdfContext(0), vg.SdfContext(0)
     a.add_counters(3, 1000, 123456789012)
     a.add_counters(1, 1, 1)
     b.add_counters(10, 20, 30)
-    assert vg.reduce_counters([a]) == (4, 1001, 123456789013)          # RCCL, world 1
-    assert vg.reduce_counters([a, b]) == (14, 1021, 123456789043)      # shared device: host sum
+    assert vg.reduce_counters([a], strict=True) == (4, 1001, 123456789013)   # RCCL, world 1
+    assert vg.reduce_counters([a]) == (4, 1001, 123456789013) and vg.reduce_path(a) == "host: one context"
+    assert vg.reduce_counters([a, b]) == (14, 1021, 123456789043)            # shared device: host sum
+    assert vg.reduce_path(a) == "host: contexts share a device"
+    with pytest.raises(vg.VgsdfError):
+        vg.reduce_counters([a, b], strict=True)                               # RCCL refuses two ranks on one device
     a.reset_counters()
     assert vg.reduce_counters([a]) == (0, 0, 0)
-    if vg.device_count() > 1:                                          # (an 8-GPU node: a real communicator)
+    if vg.device_count() > 1:                                                 # (an 8-GPU node: a real communicator)
         c = vg.SdfContext(1)
         c.add_counters(5, 6, 7)
-        assert vg.reduce_counters([b, c]) == (15, 26, 37)
+        assert vg.reduce_counters([b, c]) == (15, 26, 37) and vg.reduce_path(b) == "rccl"
         c.close()
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_a_failing_collective_does_not_cost_the_render(vg, monkeypatch):
+    """a missing / misbehaving librccl must not throw a finished render away.  The sum of 24 bytes the host
+    already holds falls back to the host and says so.  One GPU here, so the lanes are DECLARED distinct
+    (VGSDF_TEST_ASSUME_DISTINCT): (a) RCCL switched off — as if it could not be loaded; (b) the real library refusing the
+    communicator (two ranks on one device)."""
+    from conftest import FIRA
+    m = vg.FontManager(True)
+    m.add_font_with_name("Fira Sans Regular", [FIRA])
+    single = vg.DummyWriter()
+    m.render_glyphs(single, vg.Renderer.new_precise(0))
+    multi = vg.Renderer.new_multi([0, 0])
+    monkeypatch.setenv("VGSDF_TEST_ASSUME_DISTINCT", "1")
+    for no_rccl, needle in (("1", "VGSDF_NO_RCCL"), ("0", "ncclCommInitAll")):
+        monkeypatch.setenv("VGSDF_NO_RCCL", no_rccl)
+        w = vg.DummyWriter()
+        m.render_glyphs(w, multi)                       # does not raise
+        assert w.files == single.files
+        t = m.timings()
+        assert m.reduced_counters() == (256, t["glyphs"], t["pixels"])
+        path = multi.reduce_path()
+        assert path.startswith("host: RCCL fallback: ") and needle in path, path
+    monkeypatch.delenv("VGSDF_TEST_ASSUME_DISTINCT")
+    m.render_glyphs(vg.DummyWriter(), multi)
+    assert multi.reduce_path() == "host: contexts share a device"
+    multi.close()

@@ -167,4 +167,43 @@ def test_a_glyph_beyond_the_decoders_limits_falls_back_to_the_host_reader(vg):
         files[on] = w.files
         t = mgr.timings()
         assert (t["glyf_groups"], t["glyf_fallbacks"]) == ((1, 1) if on else (0, 0))
+        # the manager remembers that the device refused this font: the next run records it with the host's reader at once
+        w2 = vg.DummyWriter()
+        mgr.render_glyphs(w2, r)
+        t = mgr.timings()
+        assert w2.files == w.files and (t["glyf_groups"], t["glyf_fallbacks"]) == (0, 0)
     assert files[True] == files[False] and len(files[True]) == 256
+
+
+def test_parts_past_the_batch_bounds_fall_back_to_the_host_reader():
+    """Composite fan-out (tests/test_composite_fanout.py) sends a group to the host's reader BEFORE anything is uploaded.  With
+    the byte bound turned down to 4 KB (VG_GLYF_PARTS_LIMIT, read once per process: a child) every group of Fira Sans takes
+    that path: the files still carry the golden SHA-256s, one fallback is counted, the second run skips the glyf form."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import hashlib, json, sys
+sys.path.insert(0, "tests")
+from conftest import load_product, FIRA
+vg = load_product()
+golden = json.load(open("tests/golden/pbf_sha256.json"))["fira"]
+m = vg.FontManager(True)
+fid = m.add_font_with_name("Fira Sans Regular", [FIRA])
+r = vg.Renderer.new_precise(0)
+out = []
+for run in range(2):
+    w = vg.DummyWriter()
+    m.render_glyphs(w, r)
+    bad = [s for s, h in golden.items() if hashlib.sha256(w.files[f"{fid}/{s}-{int(s) + 255}.pbf"]).hexdigest() != h]
+    t = m.timings()
+    out.append([len(bad), t["glyf_groups"], t["glyf_fallbacks"]])
+print(json.dumps(out))
+'''
+    env = dict(os.environ, VG_GLYF_PARTS_LIMIT="4096")
+    cp = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    assert json.loads(cp.stdout.strip().splitlines()[-1]) == [[0, 0, 1], [0, 0, 0]]

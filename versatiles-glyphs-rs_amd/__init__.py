@@ -9,7 +9,7 @@ The directory name contains hyphens; load it by path (see tests/conftest.py:load
 """
 from .build import build, lib_path  # noqa: F401
 from .device import (  # noqa: F401
-    Batch, DeviceBatch, OUTLINE_CMD_DTYPE, RECT_DTYPE, SdfContext, VgsdfError, device_count, make_batch, load_library, reduce_counters,
+    Batch, DeviceBatch, OUTLINE_CMD_DTYPE, RECT_DTYPE, SdfContext, VgsdfError, device_count, make_batch, load_library, reduce_counters, reduce_path,
 )
 from .host import (  # noqa: F401
     DummyWriter, FontManager, GlyphBatchHost, NativeWriter, PbfGlyph, Renderer, encode_codeblocks, name_to_id, parse_font_name,

@@ -99,6 +99,16 @@ int vg_renderer_reduce_counters(const vg_renderer *r, uint64_t counters[3])
 		return fail(e.what());
 	}
 }
+const char *vg_renderer_reduce_path(const vg_renderer *r)
+{
+	static thread_local std::string keep;
+	try {
+		keep = r->r->reduce_path();
+	} catch (const std::exception &) {
+		keep.clear();
+	}
+	return keep.c_str();
+}
 void vg_renderer_add_counters(const vg_renderer *r, int lane, uint64_t blocks, uint64_t glyphs, uint64_t pixels)
 {
 	if (lane >= 0 && (size_t)lane < r->r->n_devices())

@@ -199,6 +199,7 @@ void FontManager::invalidate_shards()
 	shard_blocks_.clear();
 	children_.clear();
 	lane_plan_ = LanePlan{};
+	glyf_refused_.clear();
 }
 
 bool FontManager::add_font_with_name(const std::string &name, const std::vector<std::string> &sources, std::string *err)
@@ -493,6 +494,11 @@ bool FontManager::record_glyf_parts(const std::string &font_id, GlyfPartsBatch &
 		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
 			if (const FontFileEntry *f = b.glyphs[ci])
 				Renderer::record_parts(f->face(), b.start_index + ci, out);
+		if (out.overflow) {
+			if (err)
+				*err = "font " + font_id + ": the glyf parts of a glyph pass the batch bounds (composite fan-out): not a batch for the device's decoder";
+			return false;
+		}
 	}
 	return true;
 }
@@ -1065,7 +1071,7 @@ void FontManager::fe_make_slices(const std::vector<Todo> &tasks, FeGroup &G, uin
 // The group's glyphs for the device's glyf decoder (vgsdf_outlines_glyf): the workers look every glyph up and copy the
 // arrays of its simple glyphs as they stand — no point is decoded on the host (0.56 us of CPU per glyph with the
 // recorder below, ~0.1 here).  Same slices, same merge in task order as fe_record.
-void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
+bool FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 {
 	constexpr uint32_t kSlice = 64;
 	ThreadPool &tp = pool();
@@ -1087,6 +1093,19 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 	}, true);
 	const double t1 = now_s();
 	timings_.tessellate_s += t1 - t0;
+	// a worker's batch stays below 2^26 bytes / slots (Face::glyph_parts); the merged batch must fit 32-bit offsets too
+	{
+		uint64_t bytes = 0, slots = 0, n_p = 0;
+		bool overflow = false;
+		for (const Worker &w : workers_) {
+			overflow = overflow || w.plocal.overflow;
+			bytes += w.plocal.bytes.size();
+			slots += w.plocal.slots;
+			n_p += w.plocal.parts.size();
+		}
+		if (overflow || bytes >= (1ull << 31) || slots >= (1ull << 31) || n_p >= (1ull << 31))
+			return false;
+	}
 
 	static const bool trace_pack = std::getenv("VG_TRACE_PACK") != nullptr;
 	// merge in task order: jobs, command slots, parts and bytes of a slice are contiguous in its worker's batch
@@ -1150,6 +1169,7 @@ void FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 		std::fprintf(stderr, "[pack] slices %zu jobs %u parts %u bytes %u: sums %.1f us, layout %.1f, copy fork %.1f, common %.1f\n", slices.size(), n_jobs,
 		             n_parts, n_bytes, (tp0 - t1) * 1e6, (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (now_s() - tp2) * 1e6);
 	timings_.pack_s += now_s() - t1;
+	return true;
 }
 
 // jobs of a task are contiguous in the merged batch: [task_g0[t], task_g0[t + 1]); the first glyph of a block leaves room
@@ -1176,10 +1196,13 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool all
 	if (allow_glyf && glyf_on_device_) {
 		bool all_glyf = true;
 		for (size_t t = G.g0; t < G.g1 && all_glyf; t++)
-			all_glyf = tasks[t].block.all_glyf;
+			all_glyf = tasks[t].block.all_glyf && !glyf_refused_.count(tasks[t].name);
 		if (all_glyf) {
-			fe_record_glyf(tasks, G);
-			return;
+			if (fe_record_glyf(tasks, G))
+				return;
+			for (size_t t = G.g0; t < G.g1; t++) // composite fan-out past the batch bounds: the host's reader from now on
+				glyf_refused_.insert(tasks[t].name);
+			timings_.glyf_fallbacks++;
 		}
 	}
 	constexpr uint32_t kSlice = 64;
@@ -1496,7 +1519,14 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 				// rest of a composite skipped) are the host reader's — the group is recorded there and rendered again, now
 				early = false;
 				timings_.glyf_fallbacks++;
+				for (size_t tk = G.g0; tk < G.g1; tk++) // (later groups and runs of these fonts skip the glyf form)
+					glyf_refused_.insert(tasks[tk].name);
+				const std::vector<uint32_t> g0_before = G.task_g0;
 				fe_record(tasks, G, false);
+				// the pieces prepared above (files of the empty blocks, list of the others) depend on which jobs a task has: both
+				// recorders must look up the same glyphs
+				if (G.task_g0 != g0_before)
+					throw std::runtime_error("render_glyphs: the host's reader and the glyf parts disagree on a group's glyphs");
 				t = now_s();
 				renderer.submit_outlines((int)(k & 1), G.m.view(), G.out);
 				renderer.wait_outlines((int)(k & 1), G.rects, G.out, G.out_bytes, G.n_segs, G.n_jobs, G.in_place ? &G.pbf_at : nullptr);

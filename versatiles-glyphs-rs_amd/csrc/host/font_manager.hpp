@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -317,7 +318,11 @@ private:
 	};
 	FeGroup fe_group_[2]; // two groups in flight: one on the GPU, one being recorded / encoded
 	void fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool allow_glyf = true);
-	void fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G);
+	bool fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G); // false: not a batch for the device's decoder (fan-out past 32-bit offsets)
+	// fonts (by id) one of whose groups the device's glyf decoder refused (VGSDF_E_GLYF) or whose parts passed the batch bounds:
+	// later groups and runs record them with the host's reader at once instead of paying the double path again; cleared
+	// with the shard tables when a font is added
+	std::set<const std::string *> glyf_refused_;
 	void fe_make_slices(const std::vector<Todo> &tasks, FeGroup &G, uint32_t per_slice);
 	void fe_layout_common(const std::vector<Todo> &tasks, FeGroup &G); // task_g0, pbf_pre of the merged batch
 	void fe_encode_write(const std::vector<Todo> &tasks, FeGroup &G, Writer &writer);

@@ -194,6 +194,13 @@ void Renderer::reduce_counters(uint64_t out[3]) const
 		throw std::runtime_error(std::string("vgsdf_reduce_counters: ") + vgsdf_last_error(ctx_));
 }
 
+std::string Renderer::reduce_path() const
+{
+	if (mode_ != Mode::Hip)
+		return "";
+	return vgsdf_reduce_path(device_lane(0).ctx_);
+}
+
 Renderer::~Renderer()
 {
 	if (ctx2_)
@@ -326,7 +333,7 @@ bool Renderer::record_parts(const Face &face, uint32_t index, GlyfPartsBatch &ba
 	if (!glyph_id)
 		return false;
 	const double scale = (double)GLYPH_SIZE / (double)face.units_per_em(); // :107
-	(void)face.glyph_parts(*glyph_id, batch.parts, batch.bytes, batch.slots); // :109-111: the outline, undecoded
+	(void)face.glyph_parts(*glyph_id, batch.parts, batch.bytes, batch.slots, &batch.overflow); // :109-111: the outline, undecoded
 	const double advance_float = (double)face.glyph_hor_advance(*glyph_id).value_or(0) * scale * 0.95; // :115
 	const uint32_t advance = to_u32(std::round(advance_float));                                          // :116
 	GlyphJob job;

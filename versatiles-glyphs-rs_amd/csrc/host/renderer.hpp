@@ -211,8 +211,10 @@ struct GlyfPartsBatch {
 	std::vector<uint8_t> bytes;
 	std::vector<double> scale, shift_x;
 	uint32_t slots = 0;
+	bool overflow = false; // a glyph's parts passed what 32-bit offsets address (Face::glyph_parts): not a batch for the device
 	void clear()
 	{
+		overflow = false;
 		jobs.clear();
 		slot_off.assign(1, 0);
 		part_off.assign(1, 0);
@@ -368,6 +370,8 @@ public:
 	void add_counters(uint64_t blocks, uint64_t glyphs, uint64_t pixels) const;
 	void reset_counters() const;
 	void reduce_counters(uint64_t out[3]) const;
+	// how the last reduce_counters took its sum (vgsdf_reduce_path): "rccl", "host: ...", "host: RCCL fallback: <reason>"
+	std::string reduce_path() const;
 	~Renderer();
 
 	Mode mode() const { return mode_; }

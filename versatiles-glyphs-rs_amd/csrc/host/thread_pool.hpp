@@ -62,6 +62,17 @@ public:
 			return;
 		if (n > kMaxItems)
 			throw std::runtime_error("ThreadPool::run: more than 2^24 - 1 items");
+		// one fork at a time: a second run() — from an item of the running fork, or from another thread — would overwrite the
+		// word, the function and the counts of the fork in flight
+		struct InRun {
+			std::atomic<bool> &f;
+			explicit InRun(std::atomic<bool> &flag) : f(flag)
+			{
+				if (f.exchange(true, std::memory_order_acquire))
+					throw std::logic_error("ThreadPool::run: called while a fork of this pool is running (not re-entrant)");
+			}
+			~InRun() { f.store(false, std::memory_order_release); }
+		} in_run(in_run_);
 		// (no item of the previous fork is left: its word says next == count, nobody can claim anything until the store below)
 		fn_.store(&fn, std::memory_order_relaxed);
 		done_.store(0, std::memory_order_relaxed);
@@ -165,6 +176,10 @@ private:
 					std::lock_guard<std::mutex> l(err_mu_);
 					if (!failed_.exchange(true))
 						error_ = e.what();
+				} catch (...) { // (anything else would end the process from a pool thread: std::terminate)
+					std::lock_guard<std::mutex> l(err_mu_);
+					if (!failed_.exchange(true))
+						error_ = "unknown exception in a pool item";
 				}
 			}
 			if (done_.fetch_add(take, std::memory_order_acq_rel) + take == total) { // the last items: the caller may be asleep
@@ -227,7 +242,7 @@ private:
 	std::atomic<const std::function<void(size_t, unsigned)> *> fn_{nullptr}; // published by the store to state_
 	std::atomic<uint64_t> state_{0}; // generation (16 bits) | item count (24) | next item (24)
 	std::atomic<uint32_t> done_{0};
-	std::atomic<bool> failed_{false}, stop_{false};
+	std::atomic<bool> failed_{false}, stop_{false}, in_run_{false};
 	std::string error_;
 	std::atomic<unsigned> sleepers_{0}, spinners_{0};
 };

@@ -8,6 +8,7 @@
 #include "cff.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace vg {
@@ -27,10 +28,13 @@ size_t face_directory(Bytes file)
 		return 0;
 	if (magic != 0x74746366u || !file.has(4, 8)) // 'ttcf', version, numFonts
 		return npos;
-	if (file.u32(8) == 0 || !file.has(12, 4))
+	// RawFace::parse reads the WHOLE offsets[numFonts] array (out of bounds: no face) and takes the face's offset relative
+	// to the end of that array (`checked_sub`): a face inside the header or the array is refused
+	const uint64_t n_fonts = file.u32(8);
+	if (n_fonts == 0 || 4 * n_fonts > file.size() || !file.has(12, (size_t)(4 * n_fonts)))
 		return npos;
 	const size_t at = file.u32(12);
-	if (at < 16 || !file.has(at, 4) || !is_face(file.u32(at))) // (behind the header it was read from; a face is not a collection)
+	if (at < 12 + 4 * n_fonts || !file.has(at, 4) || !is_face(file.u32(at))) // (a face is not a collection)
 		return npos;
 	return at;
 }
@@ -805,6 +809,10 @@ struct PackedCursorSink {
 	void open(size_t cmds, size_t floats, uint8_t *&kp, float *&cp)
 	{
 		const size_t k0 = kinds.size(), c0 = coords.size();
+		// (batches are addressed with 32-bit offsets: a composite that fans one glyph out to gigabytes of commands is an error,
+		// not a wrapped offset)
+		if (k0 + cmds > (1ull << 30) || c0 + floats > (1ull << 30))
+			throw std::length_error("glyph outlines: more than 2^30 commands in one batch (composite fan-out)");
 		kinds.resize(k0 + cmds);
 		coords.resize(c0 + floats);
 		kp = kinds.data() + k0;
@@ -841,6 +849,19 @@ struct PartsSink {
 	std::vector<GlyfPart> &parts;
 	std::vector<uint8_t> &bytes;
 	uint32_t &slots;
+	bool *overflow;
+	// A batch of parts is addressed with 32-bit offsets (vgsdf_glyf_part); a composite copies its simple glyphs once per
+	// LEAF of its tree, so a small font can ask for gigabytes here (one 32 KB glyph named by 140 000 components).  Past
+	// these bounds nothing more is recorded and the walk stops: the caller drops the glyf form for the batch.
+	static constexpr uint64_t kMaxBatchSlots = 1ull << 26, kMaxBatchParts = 1ull << 22;
+	static uint64_t max_batch_bytes()
+	{
+		static const uint64_t v = [] {
+			const char *e = std::getenv("VG_GLYF_PARTS_LIMIT"); // (test switch: a small bound sends ordinary fonts down the fallback)
+			return e ? std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10)) : (1ull << 26);
+		}();
+		return v;
+	}
 	bool part(Bytes body, uint16_t n_contours, float a, float b, float c, float d, float e, float f, bool plain)
 	{
 		if (!body.has(0, (size_t)n_contours * 2))
@@ -862,6 +883,12 @@ struct PartsSink {
 		constexpr size_t kMaxEntry = 32 * 1024;
 		const bool fits = (size_t)n_contours * 2 + (body.size() - cur) <= kMaxEntry;
 		const size_t ends = fits ? (size_t)n_contours * 2 : 0, arrays = fits ? body.size() - cur : 0;
+		if ((uint64_t)bytes.size() + ends + arrays + 4 > max_batch_bytes() || (uint64_t)slots + n_points + 2ull * n_contours > kMaxBatchSlots ||
+		    parts.size() >= kMaxBatchParts) {
+			if (overflow)
+				*overflow = true;
+			return false;
+		}
 		GlyfPart p;
 		p.byte_off = (uint32_t)bytes.size(); // (a multiple of 4: padded below)
 		p.byte_len = (uint32_t)(ends + arrays);
@@ -885,12 +912,12 @@ struct PartsSink {
 };
 } // namespace
 
-bool Face::glyph_parts(uint16_t gid, std::vector<GlyfPart> &parts, std::vector<uint8_t> &bytes, uint32_t &slots) const
+bool Face::glyph_parts(uint16_t gid, std::vector<GlyfPart> &parts, std::vector<uint8_t> &bytes, uint32_t &slots, bool *overflow) const
 {
 	const auto g = glyph_data(gid);
 	if (!g)
 		return false;
-	PartsSink sink{parts, bytes, slots};
+	PartsSink sink{parts, bytes, slots, overflow};
 	GlyfWalker<PartsSink, true> w{*this, sink};
 	return w.walk(*g, 0, Affine{});
 }

@@ -85,8 +85,10 @@ public:
 	bool outline_glyph_packed(uint16_t glyph_id, std::vector<uint8_t> &kinds, std::vector<float> &coords) const;
 	// glyf fonts only (has_glyf_outlines()): the same walk up to the simple glyphs, which are not decoded but appended as
 	// parts — their bytes to `bytes` (4-aligned), their command slots counted from `slots` on.  false: ttf-parser returns
-	// None at this point (parts appended so far stay, as the callbacks delivered so far would).
-	bool glyph_parts(uint16_t glyph_id, std::vector<GlyfPart> &parts, std::vector<uint8_t> &bytes, uint32_t &slots) const;
+	// None at this point (parts appended so far stay, as the callbacks delivered so far would).  *overflow is set (and the
+	// walk stops) when the batch would pass what its 32-bit offsets address (2^26 bytes / slots, 2^22 parts per recorder): a composite
+	// copies its simple glyphs once per leaf, so a small font can fan out to gigabytes — the caller then drops the glyf form.
+	bool glyph_parts(uint16_t glyph_id, std::vector<GlyfPart> &parts, std::vector<uint8_t> &bytes, uint32_t &slots, bool *overflow = nullptr) const;
 	// ttf-parser's `tables().cmap.is_some()`; the reference refuses fonts without one (metadata.rs:104-107)
 	bool has_cmap() const { return has_cmap_; }
 	// glyph outlines this reader can emit: `glyf` + `loca`, or `CFF ` charstrings (ttf-parser's order: glyf first).

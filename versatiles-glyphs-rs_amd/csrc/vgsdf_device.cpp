@@ -82,6 +82,7 @@ struct vgsdf_ctx {
 	uint64_t counters[3] = {0, 0, 0};
 	uint64_t *d_counters = nullptr;
 	void *comm = nullptr; // ncclComm_t of the communicator this context last reduced in (owned by the cache below)
+	std::string reduce_path; // how the last vgsdf_reduce_counters with this context first took its sum (vgsdf_reduce_path)
 };
 
 struct vgsdf_dbatch {
@@ -1555,7 +1556,8 @@ struct Rccl {
 				break;
 		}
 		if (!lib) {
-			err = std::string("RCCL is not loadable (") + (dlerror() ? dlerror() : "librccl.so.1") + ")";
+			const char *why = dlerror(); // (one call: it clears the message)
+			err = std::string("RCCL is not loadable (") + (why ? why : "librccl.so.1") + ")";
 			return false;
 		}
 		auto sym = [&](const char *n) { return dlsym(lib, n); };
@@ -1600,33 +1602,17 @@ void vgsdf_reset_counters(vgsdf_ctx *ctx)
 		ctx->counters[0] = ctx->counters[1] = ctx->counters[2] = 0;
 }
 
-int vgsdf_reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3])
+namespace {
+// the all-reduce proper: contexts on n DISTINCT devices (n >= 1).  VGSDF_OK: every rank holds `want` (checked)
+int reduce_over_rccl(vgsdf_ctx **ctxs, int n, const std::vector<int> &devs, const uint64_t want[3])
 {
-	if (!ctxs || n <= 0 || !counters) {
-		if (ctxs && n > 0 && ctxs[0])
-			ctxs[0]->err = "vgsdf_reduce_counters: NULL argument";
-		return VGSDF_E_ARG;
-	}
-	for (int i = 0; i < n; i++)
-		if (!ctxs[i])
-			return VGSDF_E_ARG;
 	vgsdf_ctx *c0 = ctxs[0];
-	std::vector<int> devs((size_t)n);
-	bool distinct = true;
-	for (int i = 0; i < n; i++) {
-		devs[(size_t)i] = ctxs[i]->device;
-		for (int j = 0; j < i; j++)
-			distinct = distinct && ctxs[j]->device != ctxs[i]->device;
-	}
-	uint64_t host_sum[3] = {0, 0, 0};
-	for (int i = 0; i < n; i++)
-		for (int k = 0; k < 3; k++)
-			host_sum[k] += ctxs[i]->counters[k];
-	if (!distinct) { // lanes sharing a device: no communicator possible (see above)
-		std::memcpy(counters, host_sum, sizeof host_sum);
-		return VGSDF_OK;
-	}
 	std::lock_guard<std::mutex> lock(g_comm_mu);
+	const char *no_rccl = std::getenv("VGSDF_NO_RCCL"); // (test switch: behave as if librccl were absent)
+	if (no_rccl && no_rccl[0] == '1') {
+		c0->err = "vgsdf_reduce_counters: RCCL switched off (VGSDF_NO_RCCL=1)";
+		return VGSDF_E_HIP;
+	}
 	if (!g_rccl.load()) {
 		c0->err = "vgsdf_reduce_counters: " + g_rccl.err;
 		return VGSDF_E_HIP;
@@ -1675,13 +1661,70 @@ int vgsdf_reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3])
 		HIP_TRY(c0, hipSetDevice(c->device));
 		HIP_TRY(c0, hipMemcpyAsync(got, c->d_counters, sizeof got, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(c0, hipStreamSynchronize(c->stream));
-		if (std::memcmp(got, host_sum, sizeof got) != 0) {
+		if (std::memcmp(got, want, sizeof got) != 0) {
 			c0->err = "vgsdf_reduce_counters: the all-reduced counters of rank " + std::to_string(i) + " differ from the sum of the ranks' counters";
 			return VGSDF_E_HIP;
+		}
+	}
+	return VGSDF_OK;
+}
+
+int reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3], bool strict)
+{
+	if (!ctxs || n <= 0 || !counters) {
+		if (ctxs && n > 0 && ctxs[0])
+			ctxs[0]->err = "vgsdf_reduce_counters: NULL argument";
+		return VGSDF_E_ARG;
+	}
+	for (int i = 0; i < n; i++)
+		if (!ctxs[i])
+			return VGSDF_E_ARG;
+	vgsdf_ctx *c0 = ctxs[0];
+	std::vector<int> devs((size_t)n);
+	bool distinct = true;
+	for (int i = 0; i < n; i++) {
+		devs[(size_t)i] = ctxs[i]->device;
+		for (int j = 0; j < i; j++)
+			distinct = distinct && ctxs[j]->device != ctxs[i]->device;
+	}
+	uint64_t host_sum[3] = {0, 0, 0};
+	for (int i = 0; i < n; i++)
+		for (int k = 0; k < 3; k++)
+			host_sum[k] += ctxs[i]->counters[k];
+	// (test switch: take the RCCL branch although contexts share a device — RCCL refuses the communicator, which is how a
+	// one-GPU box exercises the fallback)
+	if (const char *e = std::getenv("VGSDF_TEST_ASSUME_DISTINCT"))
+		distinct = distinct || e[0] == '1';
+	if (!distinct) { // lanes sharing a device: no communicator possible (see above)
+		if (strict) {
+			c0->err = "vgsdf_reduce_counters_rccl: two contexts share a device (RCCL refuses two ranks on one device)";
+			return VGSDF_E_ARG;
+		}
+		c0->reduce_path = "host: contexts share a device";
+	} else if (n == 1 && !strict) {
+		c0->reduce_path = "host: one context";
+	} else {
+		const int rc = reduce_over_rccl(ctxs, n, devs, host_sum);
+		if (rc == VGSDF_OK) {
+			c0->reduce_path = "rccl";
+		} else if (strict) {
+			return rc;
+		} else {
+			// The collective carries 24 bytes the host already holds; losing a finished render to it would be absurd.  The
+			// sum is taken on the host and the reason kept, loudly: vgsdf_reduce_path() / bench.py `collectives_fallback`.
+			c0->reduce_path = "host: RCCL fallback: " + c0->err;
+			std::fprintf(stderr, "[vgsdf] %s -- run counters summed on the host\n", c0->err.c_str());
 		}
 	}
 	std::memcpy(counters, host_sum, sizeof host_sum);
 	return VGSDF_OK;
 }
+} // namespace
+
+int vgsdf_reduce_counters(vgsdf_ctx **ctxs, int n, uint64_t counters[3]) { return reduce_counters(ctxs, n, counters, false); }
+
+int vgsdf_reduce_counters_rccl(vgsdf_ctx **ctxs, int n, uint64_t counters[3]) { return reduce_counters(ctxs, n, counters, true); }
+
+const char *vgsdf_reduce_path(const vgsdf_ctx *ctx) { return ctx ? ctx->reduce_path.c_str() : ""; }
 
 } // extern "C"

@@ -59,7 +59,7 @@ VGSDF_SYMBOLS = [
     "vgsdf_batch_upload", "vgsdf_batch_launch", "vgsdf_batch_download", "vgsdf_batch_free", "vgsdf_sync",
     "vgsdf_batch_stats", "vgsdf_batch_time", "vgsdf_set_variant", "vgsdf_batch_device_output",
     "vgsdf_host_alloc", "vgsdf_host_free", "vgsdf_outlines_prepare", "vgsdf_outlines_render", "vgsdf_outlines_render_into", "vgsdf_outlines_submit", "vgsdf_outlines_submit_packed", "vgsdf_outlines_submit_glyf", "vgsdf_outlines_wait", "vgsdf_outlines_segments",
-    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters", "vgsdf_outlines_pbf_positions", "vgsdf_outlines_peek",
+    "vgsdf_add_counters", "vgsdf_reset_counters", "vgsdf_reduce_counters", "vgsdf_reduce_counters_rccl", "vgsdf_reduce_path", "vgsdf_outlines_pbf_positions", "vgsdf_outlines_peek",
 ]
 
 _lib = None
@@ -111,6 +111,9 @@ def load_library():
         L.vgsdf_reset_counters.argtypes = [vp]
         L.vgsdf_reset_counters.restype = None
         L.vgsdf_reduce_counters.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_uint64)]
+        L.vgsdf_reduce_counters_rccl.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_uint64)]
+        L.vgsdf_reduce_path.argtypes = [vp]
+        L.vgsdf_reduce_path.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -119,15 +122,22 @@ def device_count() -> int:
     return load_library().vgsdf_device_count()
 
 
-def reduce_counters(contexts):
+def reduce_counters(contexts, strict=False):
     """vgsdf_reduce_counters: (blocks, glyphs, pixels) summed over the contexts' run counters — an RCCL all-reduce when
-    the contexts sit on distinct devices (a single context included: a communicator of one rank)."""
+    two or more contexts sit on distinct devices, with the host's own sum as the flagged fallback (reduce_path tells);
+    strict=True: vgsdf_reduce_counters_rccl — through RCCL or an error (a single context: a communicator of one rank)."""
+    L = load_library()
     arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     out = (C.c_uint64 * 3)()
-    rc = load_library().vgsdf_reduce_counters(arr, len(contexts), out)
+    rc = (L.vgsdf_reduce_counters_rccl if strict else L.vgsdf_reduce_counters)(arr, len(contexts), out)
     if rc != 0:
-        raise VgsdfError(rc, (load_library().vgsdf_last_error(contexts[0]._h) or b"").decode())
+        raise VgsdfError(rc, (L.vgsdf_last_error(contexts[0]._h) or b"").decode())
     return tuple(int(v) for v in out)
+
+
+def reduce_path(context) -> str:
+    """vgsdf_reduce_path: "rccl", "host: one context", "host: contexts share a device" or "host: RCCL fallback: <reason>" """
+    return (load_library().vgsdf_reduce_path(context._h) or b"").decode()
 
 
 @dataclass

@@ -47,7 +47,7 @@ VGFONT_SYMBOLS = [
     "vg_writer_new_tar_fd", "vg_writer_new_dir", "vg_writer_write_file", "vg_writer_write_directory", "vg_writer_finish",
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
     "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
-    "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_add_counters",
+    "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_reduce_path", "vg_renderer_add_counters",
     "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device", "vg_manager_set_lane_form",
 ]
 
@@ -106,6 +106,8 @@ def _L():
         L.vg_renderer_new_multi.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.vg_renderer_device_count.argtypes = [vp]
         L.vg_renderer_reduce_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.vg_renderer_reduce_path.argtypes = [vp]
+        L.vg_renderer_reduce_path.restype = C.c_char_p
         L.vg_renderer_add_counters.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
         L.vg_renderer_add_counters.restype = None
         L.vg_renderer_reset_counters.argtypes = [vp]
@@ -200,6 +202,10 @@ class Renderer:
         if _L().vg_renderer_reduce_counters(self._h, out) != 0:
             raise RuntimeError(_err())
         return tuple(int(v) for v in out)
+
+    def reduce_path(self) -> str:
+        """how the last reduce took its sum: "rccl", "host: contexts share a device", "host: RCCL fallback: <reason>" ..."""
+        return (_L().vg_renderer_reduce_path(self._h) or b"").decode()
 
     def render_glyph(self, manager: "FontManager", font_id: str, index: int, file_index: int = 0):
         """Renderer::render_glyph(&face, index) -> PbfGlyph | None"""
