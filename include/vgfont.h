@@ -59,11 +59,12 @@ const char *vg_last_error(void);
 vg_renderer *vg_renderer_new(int mode, int device_ordinal);
 /* ONE process, n devices (the reference is one process with a rayon pool, src/font/manager.rs:81-125):
  * a HIP renderer with one lane per entry of `devices` (own device contexts and streams each; an entry may repeat a
- * device).  vg_manager_render_glyphs / _to with such a renderer deal every font's glyphs to the lanes by estimated
- * cost (vg_manager_shard_glyphs' table), render each shard on its own host thread, and merge the partial PBFs of a
- * block in this process's memory — there is no exchange step.  With at least four non-empty (font, block) tasks per
- * lane (or when vg_manager_set_lane_form says so) whole tasks are dealt out instead (manager.rs:86-97's unit, by
- * glyph count): every file comes from one lane and nothing is merged.  Output bytes equal a single-device run's either way.  The run
+ * device).  vg_manager_render_glyphs / _to with such a renderer deal the run's (font, block) tasks — manager.rs:86-97's
+ * unit — to the lanes, longest first; every lane renders its tasks on its own host thread and every file comes whole from
+ * one lane.  Where whole tasks do not balance (ONE font's 20-45 unequal blocks on 8 devices) the glyphs of the few heaviest
+ * blocks are split between lanes and those blocks' partial PBFs merged in this process's memory (the hybrid plan;
+ * vg_manager_plan_lanes shows it, vg_manager_set_lane_form chooses another form) — there is no exchange step.  Output bytes
+ * equal a single-device run's in every form.  The run
  * counters {blocks, glyphs, pixels} are summed over the lanes with vgsdf_reduce_counters (RCCL all-reduce when the
  * devices are distinct; the host's own sum, flagged in vg_renderer_reduce_path, if RCCL fails) and checked; vg_manager_reduced_counters returns them.  NULL + vg_last_error() on failure. */
 vg_renderer *vg_renderer_new_multi(const int *devices, int n);
@@ -93,9 +94,10 @@ void vg_manager_set_in_place_pbf(vg_manager *m, int on);
  * 0 = the host's reader records the callbacks (CFF / CFF2 fonts always take that way; so does a batch in which the device
  * finds a malformed entry).  Same bytes either way. */
 void vg_manager_set_glyf_on_device(vg_manager *m, int on);
-/* How a renderer of several device lanes (vg_renderer_new_multi) splits a run: -1 (default) whole (font, block) tasks per lane —
- * manager.rs:86-97's unit — unless there are fewer than four non-empty blocks per lane, 0 always glyph-level shards of every
- * font (merged afterwards), 1 always whole tasks.  Same bytes. */
+/* How a renderer of several device lanes (vg_renderer_new_multi) splits a run: -1 / 2 (default) the hybrid plan — whole
+ * (font, block) tasks per lane, manager.rs:86-97's unit, and the heaviest blocks' glyphs split between lanes until the lanes'
+ * estimated raster cost is within 4 % of the mean; 1 whole tasks only; 0 glyph-level shards of every font (every block
+ * merged afterwards).  Same bytes. */
 void vg_manager_set_lane_form(vg_manager *m, int form);
 int vg_manager_add_font_with_name(vg_manager *m, const char *name, const char *const *paths, int n_paths);
 int vg_manager_add_font_data(vg_manager *m, const char *name, const uint8_t *data, size_t len);
@@ -148,6 +150,11 @@ int vg_manager_write_families_json(const vg_manager *m, vg_writer *w);
  * quadratic flattening, control-box area), identical on every rank.  owner[65536]: rank per code point,
  * 0xFF = unmapped; cost[65536] (may be NULL): the estimates. */
 int vg_manager_shard_glyphs(const vg_manager *m, const char *font_id, uint32_t world, uint8_t *owner, double *cost);
+/* The lane plan a run on `world` device lanes would use with the present lane form (1 or hybrid), for one font of the
+ * manager: owner[65536] = lane per code point (0xFF = unmapped), *n_split_blocks = blocks of this font whose glyphs are
+ * split between lanes, *est_max_over_mean = fullest lane / mean lane in the plan's own weights (all fonts of the manager).
+ * Host arithmetic only (no device needed); the plan is kept until a font is added.  Any output pointer may be NULL. */
+int vg_manager_plan_lanes(vg_manager *m, const char *font_id, uint32_t world, uint8_t *owner, uint32_t *n_split_blocks, double *est_max_over_mean);
 /* From now on every render / build_batch / record_outlines call of this manager sees only the glyphs
  * that rank `rank` of `world` owns; every block is still emitted and its PBF holds this rank's glyphs
  * only (a partial).  world <= 1 switches sharding off. */

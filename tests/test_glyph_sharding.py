@@ -222,7 +222,7 @@ def test_shard_arguments_and_stale_tables(vg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", [0, 1, -1])
+@pytest.mark.parametrize("form", [0, 1, 2, -1])
 @pytest.mark.parametrize("devices", [[0, 0], [0] * 8])
 def test_one_process_many_device_lanes(vg, devices, form):
     """SURVEY §8e / VERDICT r2 item 2: ONE process, N device lanes behind the C ABI (vg_renderer_new_multi): the glyph
@@ -231,7 +231,8 @@ def test_one_process_many_device_lanes(vg, devices, form):
     (Noto Sans all languages) and of Fira — through the native tar sink too.  The lanes' run counters are summed by
     vgsdf_reduce_counters (host sum here: lanes that share a device cannot form an RCCL communicator).
     form 0: the fonts' glyphs are sharded over the lanes and the partial PBFs merged; form 1: the lanes take whole (font,
-    block) tasks and nothing is merged (render_tasks_multi); -1: the library chooses (whole tasks here: 91 non-empty blocks)."""
+    block) tasks and nothing is merged (render_tasks_multi); 2: whole tasks, the heaviest blocks split between lanes (the
+    hybrid plan); -1: the library chooses (the hybrid plan)."""
     import tarfile
     golden = json.loads((GOLDEN / "pbf_sha256.json").read_text())
     from conftest import FIRA
@@ -267,6 +268,33 @@ def test_one_process_many_device_lanes(vg, devices, form):
     single = vg.DummyWriter()
     m.render_glyphs(single, vg.Renderer.new_precise(0))
     assert single.files == w.files and m.reduced_counters() == (0, 0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("files", ["fira", "noto_all"])
+def test_hybrid_plan_with_split_blocks_gives_the_golden_files(vg, files):
+    """ONE font on 8 lanes: the hybrid plan splits its heaviest blocks between lanes (tests/test_lane_plan.py checks the
+    balance); the split blocks' parts are merged in the process's memory and every file carries the golden SHA-256 — both
+    dispatchers, in-place assembly on and off."""
+    golden = json.loads((GOLDEN / "pbf_sha256.json").read_text())[files]
+    from conftest import FIRA
+    m = vg.FontManager(True)
+    fid = m.add_font_with_name("Some Font", [FIRA] if files == "fira" else noto_files())
+    owner, n_split, est = m.plan_lanes(fid, 8)
+    assert n_split >= 1 and est <= 1.05
+    multi = vg.Renderer.new_multi([0] * 8)
+    for fe in (True, False):
+        for in_place in (True, False):
+            m.set_device_front_end(fe)
+            m.set_in_place_pbf(in_place)
+            w = vg.DummyWriter()
+            m.render_glyphs(w, multi)
+            assert len(w.files) == 256
+            bad = [s for s, h in golden.items() if hashlib.sha256(w.files[f"{fid}/{s}-{int(s) + 255}.pbf"]).hexdigest() != h]
+            assert not bad, (fe, in_place, bad[:5])
+            t = m.timings()
+            assert m.reduced_counters() == (256, t["glyphs"], t["pixels"])
+    multi.close()
 
 
 @pytest.mark.gpu

@@ -123,7 +123,7 @@ void vg_manager_free(vg_manager *m) { delete m; }
 void vg_manager_set_device_front_end(vg_manager *m, int on) { m->m.set_device_front_end(on != 0); }
 void vg_manager_set_in_place_pbf(vg_manager *m, int on) { m->m.set_in_place_pbf(on != 0); }
 void vg_manager_set_glyf_on_device(vg_manager *m, int on) { m->m.set_glyf_on_device(on != 0); }
-void vg_manager_set_lane_form(vg_manager *m, int form) { m->m.set_lane_form(form < 0 ? -1 : (form ? 1 : 0)); }
+void vg_manager_set_lane_form(vg_manager *m, int form) { m->m.set_lane_form(form < 0 || form > 2 ? -1 : form); }
 void vg_manager_set_threads(vg_manager *m, unsigned threads, unsigned blocks_per_batch)
 {
 	m->m.set_threads(threads);
@@ -158,6 +158,24 @@ int vg_manager_shard_glyphs(const vg_manager *m, const char *font_id, uint32_t w
 	if (cost)
 		std::memcpy(cost, sh.cost.data(), sh.cost.size() * sizeof(double));
 	return 0;
+}
+
+int vg_manager_plan_lanes(vg_manager *m, const char *font_id, uint32_t world, uint8_t *owner, uint32_t *n_split_blocks, double *est_max_over_mean)
+{
+	try {
+		std::vector<uint8_t> own;
+		uint32_t n_split = 0;
+		std::string err;
+		if (!m->m.plan_lanes(font_id, world, own, n_split, est_max_over_mean, &err))
+			return fail(err);
+		if (owner)
+			std::memcpy(owner, own.data(), own.size());
+		if (n_split_blocks)
+			*n_split_blocks = n_split;
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
 }
 
 int vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world)

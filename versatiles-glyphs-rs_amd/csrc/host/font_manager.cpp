@@ -801,74 +801,273 @@ struct CaptureWriter final : Writer {
 };
 } // namespace
 
-// Many fonts: the lanes take WHOLE (font, block) tasks — the reference's own unit (manager.rs:86-97) — dealt out by glyph
-// count, longest first; every file is rendered, assembled and captured by one lane, nothing is merged.  (One font's ~45
-// unequal non-empty blocks do not balance over 8 devices: render_glyphs_multi shards its glyphs instead.)
-void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
+// The lanes take WHOLE (font, block) tasks — the reference's own unit (manager.rs:86-97) — dealt out longest first; every
+// file is rendered, assembled and captured by one lane and nothing is merged.  One font's 20-45 unequal non-empty blocks do
+// not balance over 8 devices that way (estimated raster cost per lane up to 1.3 / 1.5 x the mean for Noto Sans Regular / all
+// files): the HYBRID plan (form 2, the default) then splits the glyphs of the few heaviest blocks between lanes — those
+// blocks' partial PBFs are merged afterwards, everything else stays whole (manager.rs:117-121 has rayon steal whole tasks;
+// with 8 devices and one font there is nothing to steal).
+void FontManager::build_lane_plan(uint32_t world, int form)
+{
+	LanePlan plan;
+	plan.world = world;
+	plan.form = form;
+	for (const auto &[name, font] : fonts_) {
+		plan.names.push_back(&name);
+		for (const GlyphBlock &b : font.blocks())
+			plan.all.push_back(Todo{&name, b});
+	}
+	const size_t n_tasks = plan.all.size();
+	// Step 1, cheap weights: a block's glyphs' outline sizes (command slots of their glyf entries + a constant per glyph; 40
+	// per glyph of a CFF font) — a stand-in for the raster's w*h*N that correlates 0.87 with it and costs one table walk
+	// per glyph on the pool.  Many fonts (hundreds of non-empty tasks) balance on it and need nothing else.
+	std::vector<double> weight(n_tasks, 0.0);
+	pool().run(n_tasks, [&](size_t i, unsigned) {
+		const GlyphBlock &blk = plan.all[i].block;
+		if (blk.is_empty())
+			return;
+		std::vector<GlyfPart> parts;
+		std::vector<uint8_t> bytes;
+		uint64_t w = 0;
+		for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+			if (const FontFileEntry *f = blk.glyphs[ci]) {
+				uint32_t slots = 32;
+				if (f->face().has_glyf_outlines()) {
+					slots = 0;
+					parts.clear();
+					bytes.clear();
+					if (const auto gid = f->face().glyph_index(blk.start_index + ci))
+						(void)f->face().glyph_parts(*gid, parts, bytes, slots);
+				}
+				w += 8 + slots;
+			}
+		weight[i] = (double)w;
+	});
+	// an item = a whole task or one part of a split task
+	struct Item {
+		uint32_t task, part, n_parts;
+		double w;
+	};
+	std::vector<Item> items;
+	for (size_t i = 0; i < n_tasks; i++)
+		if (!plan.all[i].block.is_empty())
+			items.push_back(Item{(uint32_t)i, 0, 1, weight[i]});
+	std::vector<uint32_t> item_lane;
+	std::vector<double> load;
+	auto lpt = [&]() { // longest processing time first (ties: task order, so the plan is deterministic); -> max / mean
+		std::vector<uint32_t> order(items.size());
+		for (size_t k = 0; k < items.size(); k++)
+			order[k] = (uint32_t)k;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return items[x].w > items[y].w; });
+		load.assign(world, 0.0);
+		item_lane.assign(items.size(), 0);
+		for (uint32_t k : order) {
+			const uint32_t r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+			item_lane[k] = r;
+			load[r] += items[k].w;
+		}
+		double sum = 0, mx = 0;
+		for (double l : load)
+			sum += l, mx = std::max(mx, l);
+		return sum > 0 ? mx / (sum / world) : 1.0;
+	};
+	double ratio = lpt();
+	// Step 2, hybrid: few tasks per lane (fewer than 32 non-empty blocks each: one font, or a handful, on several devices).
+	// The cheap weights are too coarse for that — they balance Noto Sans' 45 blocks over 8 lanes to 1.02 in their own
+	// measure and to 1.57 in true raster cost — and whole blocks too large.  Weights become the estimated raster cost w*h*N of every glyph (from
+	// its recorded outline: correlation 0.9996 with the true cost; the shard tables, built on the pool once per font set),
+	// and while the fullest lane is more than 4 % over the mean, the heaviest splittable item ON that lane is cut into twice
+	// as many parts (contiguous code point ranges of equal estimated cost).  A dozen iterations for one font on 8 lanes.
+	std::vector<std::vector<double>> glyph_cost; // per task, per code point of the block (hybrid only)
+	std::vector<uint32_t> task_parts(n_tasks, 1);
+	constexpr double kGood = 1.04;
+	if (form == 2 && world > 1 && items.size() < 32u * world) {
+		plan.accurate = true;
+		glyph_cost.resize(n_tasks);
+		size_t t0 = 0;
+		for (const auto &[name, font] : fonts_) {
+			const GlyphShard &sh = cached_shard(name, font, world);
+			const size_t nb = font.blocks().size();
+			for (size_t bi = 0; bi < nb; bi++) {
+				const GlyphBlock &blk = plan.all[t0 + bi].block;
+				if (blk.is_empty())
+					continue;
+				std::vector<double> &gc = glyph_cost[t0 + bi];
+				gc.assign(GLYPH_BLOCK_SIZE, 0.0);
+				double w = 0;
+				for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+					if (blk.glyphs[ci]) {
+						gc[ci] = std::max(1.0, sh.cost[blk.start_index + ci]);
+						w += gc[ci];
+					}
+				weight[t0 + bi] = w;
+			}
+			t0 += nb;
+		}
+		for (Item &it : items)
+			it.w = weight[it.task];
+		// cost of part p of n of a task: the glyphs whose cumulative cost (up to and including their own) falls into
+		// ((p / n) W, ((p + 1) / n) W]
+		auto part_of = [&](uint32_t task, double cum, uint32_t n) {
+			const double W = weight[task];
+			uint32_t p = (uint32_t)std::ceil(cum / W * n) - 1;
+			return std::min(p, n - 1);
+		};
+		auto rebuild_items = [&]() {
+			items.clear();
+			for (size_t i = 0; i < n_tasks; i++) {
+				if (plan.all[i].block.is_empty())
+					continue;
+				const uint32_t n = task_parts[i];
+				if (n == 1) {
+					items.push_back(Item{(uint32_t)i, 0, 1, weight[i]});
+					continue;
+				}
+				std::vector<double> pw(n, 0.0);
+				double cum = 0;
+				for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+					if (glyph_cost[i][ci] > 0) {
+						cum += glyph_cost[i][ci];
+						pw[part_of((uint32_t)i, cum, n)] += glyph_cost[i][ci];
+					}
+				for (uint32_t p = 0; p < n; p++)
+					if (pw[p] > 0)
+						items.push_back(Item{(uint32_t)i, p, n, pw[p]});
+			}
+		};
+		for (int iter = 0; iter < 256; iter++) {
+			ratio = lpt();
+			if (ratio <= kGood)
+				break;
+			const uint32_t full = (uint32_t)(std::max_element(load.begin(), load.end()) - load.begin());
+			// the heaviest item of the fullest lane whose task can still be cut finer
+			int best = -1;
+			for (size_t k = 0; k < items.size(); k++)
+				if (item_lane[k] == full && 2 * task_parts[items[k].task] <= plan.all[items[k].task].block.len() &&
+				    (best < 0 || items[k].w > items[(size_t)best].w))
+					best = (int)k;
+			if (best < 0)
+				break;
+			task_parts[items[(size_t)best].task] *= 2;
+			rebuild_items();
+		}
+		ratio = lpt();
+		// the parts' glyph subsets
+		for (size_t i = 0; i < n_tasks; i++) {
+			const uint32_t n = task_parts[i];
+			if (n == 1)
+				continue;
+			const GlyphBlock &blk = plan.all[i].block;
+			std::vector<GlyphBlock> sub(n);
+			for (GlyphBlock &sb : sub)
+				sb.start_index = blk.start_index;
+			double cum = 0;
+			for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+				if (blk.glyphs[ci]) {
+					cum += glyph_cost[i][ci];
+					sub[part_of((uint32_t)i, cum, n)].set_glyph_font((uint8_t)ci, blk.glyphs[ci]);
+				}
+			LanePlan::Split sp{(uint32_t)i, (uint32_t)plan.part_blocks.size(), 0};
+			for (GlyphBlock &sb : sub)
+				if (!sb.is_empty()) {
+					plan.part_blocks.push_back(std::move(sb));
+					sp.n_parts++;
+				}
+			plan.splits.push_back(sp);
+		}
+	}
+	plan.est_max_over_mean = ratio;
+	// lanes: whole tasks and parts in task order; empty blocks go round
+	plan.owner.assign(n_tasks, 0);
+	plan.slot.assign(n_tasks, 0);
+	plan.part_owner.assign(plan.part_blocks.size(), 0);
+	plan.part_slot.assign(plan.part_blocks.size(), 0);
+	plan.lane_tasks.resize(world);
+	plan.lane_blocks.assign(world, 0);
+	std::vector<int> split_of(n_tasks, -1);
+	for (size_t k = 0; k < plan.splits.size(); k++)
+		split_of[plan.splits[k].task] = (int)k;
+	// lane of every (task, live part): items list the parts with glyphs in ascending part order, as part_blocks does
+	std::vector<std::vector<uint32_t>> lanes_of(n_tasks);
+	for (size_t k = 0; k < items.size(); k++)
+		lanes_of[items[k].task].push_back(item_lane[k]);
+	uint32_t rr = 0;
+	for (size_t i = 0; i < n_tasks; i++) {
+		if (plan.all[i].block.is_empty()) {
+			const uint32_t r = rr++ % world;
+			plan.owner[i] = r;
+			plan.slot[i] = (uint32_t)plan.lane_tasks[r].size();
+			plan.lane_tasks[r].push_back(plan.all[i]);
+			plan.lane_blocks[r]++;
+		} else if (split_of[i] < 0) {
+			const uint32_t r = lanes_of[i].at(0);
+			plan.owner[i] = r;
+			plan.slot[i] = (uint32_t)plan.lane_tasks[r].size();
+			plan.lane_tasks[r].push_back(plan.all[i]);
+			plan.lane_blocks[r]++;
+		} else {
+			const LanePlan::Split &sp = plan.splits[(size_t)split_of[i]];
+			if (lanes_of[i].size() != sp.n_parts)
+				throw std::logic_error("lane plan: a split block's parts and items disagree");
+			plan.owner[i] = LanePlan::kSplit;
+			plan.slot[i] = (uint32_t)split_of[i];
+			for (uint32_t pi = 0; pi < sp.n_parts; pi++) {
+				const uint32_t r = lanes_of[i][pi];
+				plan.part_owner[sp.first_part + pi] = r;
+				plan.part_slot[sp.first_part + pi] = (uint32_t)plan.lane_tasks[r].size();
+				plan.lane_tasks[r].push_back(Todo{plan.all[i].name, plan.part_blocks[sp.first_part + pi]});
+				if (pi == 0)
+					plan.lane_blocks[r]++;
+			}
+		}
+	}
+	lane_plan_ = std::move(plan);
+}
+
+bool FontManager::plan_lanes(const std::string &font_id, uint32_t world, std::vector<uint8_t> &owner, uint32_t &n_split_blocks, double *est_max_over_mean,
+                             std::string *err)
+{
+	if (fonts_.find(font_id) == fonts_.end() || world == 0 || world > 254) {
+		if (err)
+			*err = fonts_.find(font_id) == fonts_.end() ? "unknown font id " + font_id : "plan_lanes: world must be 1..254";
+		return false;
+	}
+	const int form = lane_form_ == 1 ? 1 : 2;
+	if (lane_plan_.world != world || lane_plan_.form != form)
+		build_lane_plan(world, form);
+	const LanePlan &plan = lane_plan_;
+	owner.assign(0x10000, 0xFF);
+	n_split_blocks = 0;
+	for (size_t i = 0; i < plan.all.size(); i++) {
+		if (*plan.all[i].name != font_id || plan.all[i].block.is_empty())
+			continue;
+		const GlyphBlock &blk = plan.all[i].block;
+		if (plan.owner[i] != LanePlan::kSplit) {
+			for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+				if (blk.glyphs[ci])
+					owner[blk.start_index + ci] = (uint8_t)plan.owner[i];
+			continue;
+		}
+		n_split_blocks++;
+		const LanePlan::Split &sp = plan.splits[plan.slot[i]];
+		for (uint32_t pi = 0; pi < sp.n_parts; pi++) {
+			const GlyphBlock &pb = plan.part_blocks[sp.first_part + pi];
+			for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
+				if (pb.glyphs[ci])
+					owner[pb.start_index + ci] = (uint8_t)plan.part_owner[sp.first_part + pi];
+		}
+	}
+	if (est_max_over_mean)
+		*est_max_over_mean = plan.est_max_over_mean;
+	return true;
+}
+
+void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer, int form)
 {
 	const double t_start = now_s();
 	const uint32_t world = (uint32_t)renderer.n_devices();
-	if (lane_plan_.world != world) { // (a font set's plan is kept: the sort of its 256 blocks per font costs as much as a small run)
-		LanePlan plan;
-		plan.world = world;
-		for (const auto &[name, font] : fonts_) {
-			plan.names.push_back(&name);
-			for (const GlyphBlock &b : font.blocks())
-				plan.all.push_back(Todo{&name, b});
-		}
-		// Longest processing time first; empty blocks go round.  A block's weight: its glyphs' outline sizes (command slots
-		// of their glyf entries + a constant per glyph; 40 per glyph of a CFF font) — a cheap stand-in for the raster's
-		// w*h*N that correlates 0.87 with it: with the glyph COUNT as weight the estimated raster cost per lane is up to
-		// 1.6 / 2.5 x the mean for Noto Sans Regular / all files on 8 lanes, with this weight 1.3 / 1.5 (the estimate
-		// itself as weight: 1.1 / 1.4 — at 28 / 45 non-empty blocks the largest block sets the limit).  Computed on
-		// the pool, once per font set.
-		std::vector<uint64_t> weight(plan.all.size(), 0);
-		pool().run(plan.all.size(), [&](size_t i, unsigned) {
-			const GlyphBlock &blk = plan.all[i].block;
-			if (blk.is_empty())
-				return;
-			std::vector<GlyfPart> parts;
-			std::vector<uint8_t> bytes;
-			uint64_t w = 0;
-			for (uint32_t ci = 0; ci < GLYPH_BLOCK_SIZE; ci++)
-				if (const FontFileEntry *f = blk.glyphs[ci]) {
-					uint32_t slots = 32;
-					if (f->face().has_glyf_outlines()) {
-						slots = 0;
-						parts.clear();
-						bytes.clear();
-						if (const auto gid = f->face().glyph_index(blk.start_index + ci))
-							(void)f->face().glyph_parts(*gid, parts, bytes, slots);
-					}
-					w += 8 + slots;
-				}
-			weight[i] = w;
-		});
-		std::vector<uint32_t> order(plan.all.size());
-		for (size_t i = 0; i < plan.all.size(); i++)
-			order[i] = (uint32_t)i;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
-		std::vector<uint64_t> load(world, 0);
-		plan.owner.assign(plan.all.size(), 0);
-		uint32_t rr = 0;
-		for (uint32_t i : order) {
-			uint32_t r;
-			if (plan.all[i].block.is_empty()) {
-				r = rr++ % world;
-			} else {
-				r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
-				load[r] += weight[i];
-			}
-			plan.owner[i] = r;
-		}
-		plan.lane_tasks.resize(world);
-		plan.slot.resize(plan.all.size()); // position of task i among its lane's tasks
-		for (size_t i = 0; i < plan.all.size(); i++) {
-			plan.slot[i] = (uint32_t)plan.lane_tasks[plan.owner[i]].size();
-			plan.lane_tasks[plan.owner[i]].push_back(plan.all[i]);
-		}
-		lane_plan_ = std::move(plan);
-	}
+	if (lane_plan_.world != world || lane_plan_.form != form) // (a font set's plan is kept: building it costs as much as a small run)
+		build_lane_plan(world, form);
 	std::vector<Todo> &all = lane_plan_.all;
 	const std::vector<const std::string *> &names = lane_plan_.names;
 	const std::vector<uint32_t> &owner = lane_plan_.owner, &slot = lane_plan_.slot;
@@ -888,13 +1087,32 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 		if (parts[r].files.size() != lane_tasks[r].size())
 			throw std::runtime_error("render_glyphs: a device lane produced " + std::to_string(parts[r].files.size()) + " files instead of " +
 			                         std::to_string(lane_tasks[r].size()));
+	// the split blocks: their parts hold disjoint glyph subsets of one block and are merged into the block's file
+	const std::vector<LanePlan::Split> &splits = lane_plan_.splits;
+	std::vector<std::vector<uint8_t>> merged(splits.size());
+	if (!splits.empty())
+		pool().run(splits.size(), [&](size_t k, unsigned) {
+			std::vector<std::pair<const uint8_t *, size_t>> ps;
+			for (uint32_t pi = 0; pi < splits[k].n_parts; pi++) {
+				const CaptureWriter &lane = parts[lane_plan_.part_owner[splits[k].first_part + pi]];
+				const uint32_t at = lane_plan_.part_slot[splits[k].first_part + pi];
+				ps.emplace_back(lane.data(at), lane.size(at));
+			}
+			merged[k] = merge_pbf_partials(ps);
+		});
+	const double t_merged = now_s();
 	timings_ = RenderTimings{};
 	for (const std::string *name : names)
 		writer.write_directory(*name + "/");
 	std::string path;
 	for (size_t i = 0; i < all.size(); i++) {
-		const CaptureWriter &lane = parts[owner[i]];
 		all[i].block.path_into(*all[i].name, path);
+		if (owner[i] == LanePlan::kSplit) {
+			writer.write_bytes(path, merged[slot[i]].data(), merged[slot[i]].size());
+			timings_.pbf_bytes += merged[slot[i]].size();
+			continue;
+		}
+		const CaptureWriter &lane = parts[owner[i]];
 		writer.write_bytes(path, lane.data(slot[i]), lane.size(slot[i]));
 		timings_.pbf_bytes += lane.size(slot[i]);
 	}
@@ -902,7 +1120,7 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 	uint64_t want[3] = {all.size(), 0, 0};
 	for (uint32_t r = 0; r < world; r++) {
 		const RenderTimings &ct = children_[r]->timings_;
-		renderer.device_lane(r).add_counters(lane_tasks[r].size(), ct.glyphs, ct.pixels);
+		renderer.device_lane(r).add_counters(lane_plan_.lane_blocks[r], ct.glyphs, ct.pixels);
 		want[1] += ct.glyphs;
 		want[2] += ct.pixels;
 		timings_.tessellate_s = std::max(timings_.tessellate_s, ct.tessellate_s);
@@ -921,7 +1139,8 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer)
 		throw std::runtime_error("render_glyphs: the reduced run counters differ from the lanes' own");
 	timings_.blocks = all.size();
 	timings_.pack_s += t_sharded - t_start;
-	timings_.write_s = t_written - t_rendered;
+	timings_.encode_s += t_merged - t_rendered; // merge of the split blocks' parts
+	timings_.write_s = t_written - t_merged;
 	timings_.total_s = now_s() - t_start;
 }
 
@@ -945,17 +1164,14 @@ void FontManager::render_glyphs_multi(Writer &writer, const Renderer &renderer)
 		c->batch_blocks_set_ = batch_blocks_set_;
 		c->set_threads(per_lane);
 	}
-	// whole tasks per lane unless there are too few of them to go round (fewer than 4 non-empty blocks per lane: a small
-	// font on many devices); set_lane_form / VG_LANE_TASKS=0 / 1 forces one form
+	// Lane form: 2 (default) = whole (font, block) tasks, the heaviest blocks split between lanes where whole tasks do not
+	// balance (hybrid); 1 = whole tasks only; 0 = every font's glyphs sharded over the lanes and every block merged.
+	// set_lane_form / VG_LANE_TASKS = 0 / 1 / 2 forces one.
 	{
-		size_t busy = 0;
-		for (const auto &kv : fonts_)
-			for (const GlyphBlock &b : kv.second.blocks())
-				busy += !b.is_empty();
 		static const char *force = std::getenv("VG_LANE_TASKS");
-		const int form = lane_form_ >= 0 ? lane_form_ : (force ? (force[0] == '1') : -1);
-		if (form >= 0 ? form == 1 : busy >= 4u * world) {
-			render_tasks_multi(writer, renderer);
+		const int form = lane_form_ >= 0 ? lane_form_ : (force && force[0] >= '0' && force[0] <= '2' ? force[0] - '0' : 2);
+		if (form != 0) {
+			render_tasks_multi(writer, renderer, form);
 			return;
 		}
 	}

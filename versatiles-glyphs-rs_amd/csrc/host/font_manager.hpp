@@ -14,6 +14,7 @@
 #include <array>
 #include <cstdint>
 #include <functional>
+#include <deque>
 #include <map>
 #include <set>
 #include <memory>
@@ -261,11 +262,30 @@ private:
 	// render_tasks_multi: which lane takes which (font, block) task; kept until a font is added (invalidate_shards)
 	struct LanePlan {
 		uint32_t world = 0;
-		std::vector<Todo> all;
+		int form = -1;                             // 1: whole tasks only, 2: hybrid (the heaviest blocks split between lanes)
+		std::vector<Todo> all;                     // the (font, block) tasks in output order
 		std::vector<const std::string *> names;
-		std::vector<uint32_t> owner, slot;
+		static constexpr uint32_t kSplit = 0xFFFFFFFFu;
+		std::vector<uint32_t> owner, slot;         // whole task i: its lane and its position among the lane's files;
+		                                           // split task: owner = kSplit, slot = index into `splits`
+		struct Split {
+			uint32_t task, first_part, n_parts;    // parts [first_part, first_part + n_parts) of part_owner / part_slot / part_blocks
+		};
+		std::vector<Split> splits;
+		std::vector<uint32_t> part_owner, part_slot;
+		std::deque<GlyphBlock> part_blocks;        // the parts' glyph subsets (a Todo refers to its block)
 		std::vector<std::vector<Todo>> lane_tasks;
+		std::vector<uint32_t> lane_blocks;         // blocks credited to a lane's counters: its whole tasks + the first parts it holds
+		bool accurate = false;                     // weights are the estimated w*h*N per glyph (else: outline sizes)
+		double est_max_over_mean = 1.0;            // of the lanes' summed weights
 	};
+	void build_lane_plan(uint32_t world, int form);
+public:
+	// Which lane renders which code point of `font_id` on `world` lanes (owner[65536], 0xFF = unmapped) under the plan
+	// render_glyphs would use with the present lane form, and how many of the font's blocks are split between lanes.
+	// Needs no device: the plan is host arithmetic over the fonts' outlines.
+	bool plan_lanes(const std::string &font_id, uint32_t world, std::vector<uint8_t> &owner, uint32_t &n_split_blocks, double *est_max_over_mean, std::string *err);
+private:
 	LanePlan lane_plan_;
 	// shard tables, built once per (font, world, number of files) — on the pool — and shared with the lanes
 	struct ShardEntry {
@@ -279,7 +299,7 @@ private:
 	void invalidate_shards();
 	uint64_t reduced_[3] = {0, 0, 0};
 	void run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
-	void render_tasks_multi(Writer &writer, const Renderer &renderer); // N device lanes, whole (font, block) tasks each
+	void render_tasks_multi(Writer &writer, const Renderer &renderer, int form); // N device lanes: whole (font, block) tasks, the heaviest split (form 2)
 	void run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer);
 	// tessellate tasks [t0, t1) on the pool and pack them (task order, ascending id) into `out`
 	void tessellate_and_pack(const std::vector<Todo> &tasks, size_t t0, size_t t1, std::vector<Slice> &slices,

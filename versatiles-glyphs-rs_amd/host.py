@@ -48,7 +48,7 @@ VGFONT_SYMBOLS = [
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
     "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
     "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_reduce_path", "vg_renderer_add_counters",
-    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device", "vg_manager_set_lane_form",
+    "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device", "vg_manager_set_lane_form", "vg_manager_plan_lanes",
 ]
 
 _bound = False
@@ -75,6 +75,7 @@ def _L():
         L.vg_manager_set_glyf_on_device.restype = None
         L.vg_manager_set_lane_form.argtypes = [vp, C.c_int]
         L.vg_manager_set_lane_form.restype = None
+        L.vg_manager_plan_lanes.argtypes = [vp, C.c_char_p, C.c_uint32, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.vg_manager_add_font_with_name.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
         L.vg_manager_add_font_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
         L.vg_manager_add_path.argtypes = [vp, C.c_char_p]
@@ -290,7 +291,8 @@ class FontManager:
         _L().vg_manager_set_glyf_on_device(self._h, 1 if on else 0)
 
     def set_lane_form(self, form: int):
-        """several device lanes: -1 automatic, 0 glyph-level shards + merge, 1 whole (font, block) tasks per lane"""
+        """several device lanes: -1 / 2 hybrid (whole (font, block) tasks, the heaviest blocks split between lanes), 1 whole tasks
+        only, 0 glyph-level shards of every font + merge"""
         _L().vg_manager_set_lane_form(self._h, int(form))
 
     def set_device_front_end(self, on: bool):
@@ -368,6 +370,15 @@ class FontManager:
         if _L().vg_manager_shard_glyphs(self._h, font_id.encode(), world, owner.ctypes.data, cost.ctypes.data) != 0:
             raise RuntimeError(_err())
         return owner, cost
+
+    def plan_lanes(self, font_id: str, world: int):
+        """-> (lane per code point u8[65536] with 0xFF = unmapped, number of this font's blocks split between lanes, the plan's own
+        max / mean of the lanes' weights): what a run on `world` device lanes would do (no device needed)"""
+        owner = np.empty(65536, dtype=np.uint8)
+        n_split, ratio = C.c_uint32(0), C.c_double(0.0)
+        if _L().vg_manager_plan_lanes(self._h, font_id.encode(), world, owner.ctypes.data, C.byref(n_split), C.byref(ratio)) != 0:
+            raise RuntimeError(_err())
+        return owner, int(n_split.value), float(ratio.value)
 
     def set_glyph_shard(self, rank: int, world: int):
         """Later render / build_batch calls see only rank's glyphs (world <= 1: off)."""
