@@ -162,6 +162,10 @@ int vg_manager_set_glyph_shard(vg_manager *m, uint32_t rank, uint32_t world); /*
 /* Merges partial PBFs of ONE block (disjoint glyph subsets, same name and range) into the block's PBF:
  * glyphs in ascending id, byte for byte what a single process encodes.  Returns the needed size. */
 long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap);
+/* the same for parts that hold CONSECUTIVE runs of the block's code points, given in order (the split blocks of the hybrid
+ * lane plan): header + the parts' entries as they are, no walk over the glyph messages; parts that are not in that form
+ * are handed to vg_pbf_merge's code */
+long vg_pbf_concat(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap);
 /* A rank's shard: only the listed block starts (multiples of 256) of one font id. */
 int vg_manager_render_blocks(vg_manager *m, vg_renderer *r, const char *font_id, const uint32_t *starts, int n,
                              vg_write_cb cb, void *user);

@@ -279,7 +279,7 @@ def test_hybrid_plan_with_split_blocks_gives_the_golden_files(vg, files):
     golden = json.loads((GOLDEN / "pbf_sha256.json").read_text())[files]
     from conftest import FIRA
     m = vg.FontManager(True)
-    fid = m.add_font_with_name("Some Font", [FIRA] if files == "fira" else noto_files())
+    fid = m.add_font_with_name("Fira Sans Regular", [FIRA]) if files == "fira" else m.add_font_with_name("Noto Sans Regular", noto_files())
     owner, n_split, est = m.plan_lanes(fid, 8)
     assert n_split >= 1 and est <= 1.05
     multi = vg.Renderer.new_multi([0] * 8)

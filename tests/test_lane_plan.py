@@ -69,3 +69,59 @@ def test_many_fonts_stay_whole_tasks(vg):
         for b in range(256):
             o = owner[256 * b:256 * b + 256]
             assert len(set(o[o != 0xFF].tolist())) <= 1
+
+
+def _varint(b, at):
+    v = sh = 0
+    while True:
+        c = b[at]
+        at += 1
+        v |= (c & 0x7F) << sh
+        sh += 7
+        if not c & 0x80:
+            return v, at
+
+
+def _put(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append(v & 0x7F | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_concatenating_consecutive_parts_equals_the_merge(vg):
+    """the split blocks' parts are merged by concatenation (vg_pbf_concat): same bytes as vg_pbf_merge and as the whole
+    block; parts that are not consecutive runs fall through to the merge"""
+    m = vg.FontManager(False)
+    fid = m.add_font_with_name("Fira Sans Regular", [FIRA])
+    full = m.render_block(vg.Renderer.new_dummy(), fid, 0)
+    assert full[0] == 0x0A
+    _, at = _varint(full, 1)
+    fields0 = at
+    for tag in (0x0A, 0x12):
+        assert full[at] == tag
+        n, at = _varint(full, at + 1)
+        at += n
+    fields = full[fields0:at]
+    entries = []
+    while at < len(full):
+        assert full[at] == 0x1A
+        n, nxt = _varint(full, at + 1)
+        entries.append(full[at:nxt + n])
+        at = nxt + n
+    assert len(entries) > 150
+
+    def part(es):
+        body = fields + b"".join(es)
+        return b"\x0a" + _put(len(body)) + body
+    cuts = [0, 40, 41, 120, len(entries)]
+    parts = [part(entries[a:b]) for a, b in zip(cuts, cuts[1:])] + [part([])]
+    assert vg.pbf_merge(parts, consecutive=True) == full == vg.pbf_merge(parts)
+    shuffled = [parts[2], parts[0], parts[3], parts[1]]
+    assert vg.pbf_merge(shuffled, consecutive=True) == full          # not ascending: the general merge sorts them
+    other = bytearray(parts[1])
+    other[4] ^= 1                                                     # another font name
+    with pytest.raises(RuntimeError):
+        vg.pbf_merge([parts[0], bytes(other)], consecutive=True)

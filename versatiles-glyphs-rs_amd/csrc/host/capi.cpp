@@ -203,6 +203,21 @@ long vg_pbf_merge(const uint8_t *const *parts, const size_t *lens, int n, uint8_
 	}
 }
 
+long vg_pbf_concat(const uint8_t *const *parts, const size_t *lens, int n, uint8_t *out, size_t cap)
+{
+	try {
+		std::vector<std::pair<const uint8_t *, size_t>> ps;
+		for (int i = 0; i < n; i++)
+			ps.emplace_back(parts[i], lens[i]);
+		const std::vector<uint8_t> v = vg::concat_pbf_partials(ps);
+		if (out && cap >= v.size())
+			std::memcpy(out, v.data(), v.size());
+		return (long)v.size();
+	} catch (const std::exception &e) {
+		return fail(e.what());
+	}
+}
+
 int vg_manager_scan(vg_manager *m, const char *path)
 {
 	std::string err;

@@ -759,6 +759,75 @@ std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_
 	return out;
 }
 
+// The same for parts that hold CONSECUTIVE runs of a block's code points, in order (the split blocks of the hybrid lane plan):
+// the entries of a part are already in ascending id and stay together, so the block's file is its header followed by the
+// parts' entry regions as they are — three or four copies instead of a walk over every glyph message.  The first ids of the
+// parts must ascend (checked); anything unexpected goes to merge_pbf_partials.
+std::vector<uint8_t> concat_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts)
+{
+	auto varint = [](const uint8_t *&p, const uint8_t *end, uint64_t &v) {
+		v = 0;
+		for (int sh = 0; p < end && sh < 64; sh += 7) {
+			const uint8_t b = *p++;
+			v |= (uint64_t)(b & 0x7F) << sh;
+			if (!(b & 0x80))
+				return true;
+		}
+		return false;
+	};
+	struct Region {
+		const uint8_t *p;
+		size_t n;
+	};
+	std::vector<Region> regions;
+	const uint8_t *fields = nullptr; // name + range fields of the first part
+	size_t fields_n = 0;
+	uint64_t last_first_id = 0;
+	for (const auto &part : parts) {
+		const uint8_t *p = part.first, *end = p + part.second;
+		uint64_t len;
+		if (p == end || *p++ != 0x0A || !varint(p, end, len) || len != (uint64_t)(end - p))
+			return merge_pbf_partials(parts);
+		const uint8_t *f0 = p;
+		for (int k = 0; k < 2; k++) { // 0x0A name, 0x12 range (fontstack.rs:9-25: in tag order)
+			if (p == end || *p++ != (k ? 0x12 : 0x0A) || !varint(p, end, len) || len > (uint64_t)(end - p))
+				return merge_pbf_partials(parts);
+			p += len;
+		}
+		if (!fields) {
+			fields = f0;
+			fields_n = (size_t)(p - f0);
+		} else if ((size_t)(p - f0) != fields_n || std::memcmp(f0, fields, fields_n) != 0) {
+			return merge_pbf_partials(parts); // (throws: parts of different blocks)
+		}
+		if (p == end)
+			continue; // a part without glyphs
+		const uint8_t *q = p;
+		uint64_t glen, id;
+		if (*q++ != 0x1A || !varint(q, end, glen) || q == end || *q++ != 0x08 || !varint(q, end, id) || (!regions.empty() && id <= last_first_id))
+			return merge_pbf_partials(parts);
+		last_first_id = id;
+		regions.push_back(Region{p, (size_t)(end - p)});
+	}
+	size_t stack = fields_n;
+	for (const Region &r : regions)
+		stack += r.n;
+	std::vector<uint8_t> out;
+	out.reserve(stack + 8);
+	out.push_back(0x0A);
+	for (uint64_t v = stack;; v >>= 7) {
+		if (v < 0x80) {
+			out.push_back((uint8_t)v);
+			break;
+		}
+		out.push_back((uint8_t)(v | 0x80));
+	}
+	out.insert(out.end(), fields, fields + fields_n);
+	for (const Region &r : regions)
+		out.insert(out.end(), r.p, r.p + r.n);
+	return out;
+}
+
 void FontManager::render_glyphs(Writer &writer, const Renderer &renderer)
 {
 	if (renderer.n_devices() > 1 && renderer.mode() == Renderer::Mode::Hip && !parent_) {
@@ -1098,7 +1167,7 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer, i
 				const uint32_t at = lane_plan_.part_slot[splits[k].first_part + pi];
 				ps.emplace_back(lane.data(at), lane.size(at));
 			}
-			merged[k] = merge_pbf_partials(ps);
+			merged[k] = concat_pbf_partials(ps);
 		});
 	const double t_merged = now_s();
 	timings_ = RenderTimings{};

@@ -373,5 +373,7 @@ std::string name_to_id(const std::string &name); // manager.rs:141-147
 // are and written in ascending id, so the result equals the PBF a single process encodes.  Throws
 // std::runtime_error on malformed input or when names / ranges differ.
 std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts);
+// the same for parts that hold consecutive runs of the block's code points, in order: header + the parts' entries as they are
+std::vector<uint8_t> concat_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts);
 
 } // namespace vg

@@ -46,7 +46,7 @@ VGFONT_SYMBOLS = [
     "vg_encode_codeblocks", "vg_manager_index_json", "vg_manager_families_json", "vg_writer_new_tar_path",
     "vg_writer_new_tar_fd", "vg_writer_new_dir", "vg_writer_write_file", "vg_writer_write_directory", "vg_writer_finish",
     "vg_writer_free", "vg_manager_render_glyphs_to", "vg_manager_write_index_json", "vg_manager_write_families_json",
-    "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge",
+    "vg_manager_shard_glyphs", "vg_manager_set_glyph_shard", "vg_pbf_merge", "vg_pbf_concat",
     "vg_renderer_new_multi", "vg_renderer_device_count", "vg_renderer_reduce_counters", "vg_renderer_reduce_path", "vg_renderer_add_counters",
     "vg_renderer_reset_counters", "vg_manager_reduced_counters", "vg_manager_set_in_place_pbf", "vg_manager_set_glyf_on_device", "vg_manager_set_lane_form", "vg_manager_plan_lanes",
 ]
@@ -117,6 +117,8 @@ def _L():
         L.vg_manager_reduced_counters.restype = None
         L.vg_pbf_merge.restype = C.c_long
         L.vg_pbf_merge.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t]
+        L.vg_pbf_concat.restype = C.c_long
+        L.vg_pbf_concat.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t]
         for f in (L.vg_manager_font_ids, L.vg_manager_index_json, L.vg_manager_families_json):
             f.restype = C.c_long
             f.argtypes = [vp, vp, C.c_size_t]
@@ -562,16 +564,18 @@ class NativeWriter:
             pass
 
 
-def pbf_merge(parts) -> bytes:
-    """Partial PBFs of one block (disjoint glyph subsets) -> the block's PBF."""
+def pbf_merge(parts, consecutive: bool = False) -> bytes:
+    """Partial PBFs of one block (disjoint glyph subsets) -> the block's PBF.  consecutive=True: vg_pbf_concat (parts that
+    hold consecutive runs of the block's code points, in order)."""
     parts = [bytes(p) for p in parts]
+    fn = _L().vg_pbf_concat if consecutive else _L().vg_pbf_merge
     arr = (C.c_char_p * len(parts))(*parts)
     lens = (C.c_size_t * len(parts))(*[len(p) for p in parts])
-    need = _L().vg_pbf_merge(arr, lens, len(parts), None, 0)
+    need = fn(arr, lens, len(parts), None, 0)
     if need < 0:
         raise RuntimeError(_err())
     out = np.empty(need, dtype=np.uint8)
-    _L().vg_pbf_merge(arr, lens, len(parts), out.ctypes.data, need)
+    fn(arr, lens, len(parts), out.ctypes.data, need)
     return out.tobytes()
 
 
