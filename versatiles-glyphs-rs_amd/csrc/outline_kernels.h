@@ -56,8 +56,12 @@ extern "C" {
 // parts: vgsdf_glyf_part records (include/vgsdf.h); writes the commands of every part into its slots of `cmds`;
 // error_flag bit 4: a malformed entry
 // max_cmd_cap / max_byte_len: the largest cmd_cap / byte_len among the parts (they size the launch's LDS)
+// cmd_open (may be NULL): the context pass's byte per command, written by the decoder itself — only for batches whose scales
+// are all positive and finite (bit 1 of that byte is never set here)
 int vgsdf_glyf_decode(const void *parts, uint32_t n_parts, const uint8_t *bytes, vgsdf::OutlineCmd *cmds, uint32_t *error_flag,
-                      uint32_t max_cmd_cap, uint32_t max_byte_len, hipStream_t stream);
+                      uint32_t max_cmd_cap, uint32_t max_byte_len, uint8_t *cmd_open, hipStream_t stream);
+// upload by a kernel: src_mapped = device address of a page-locked, device-mapped host block (16-byte aligned), dst 16-byte aligned
+int vgsdf_copy_in(const void *src_mapped, void *dst, size_t bytes, hipStream_t stream);
 // cmd_open: one byte per command (bit 0: ring open in front of it, bit 1: the glyph's scale is not positive finite)
 // error_flag: one zeroed word; bit 1 is raised for a command kind that is none of the five callbacks
 int vgsdf_outline_context(const vgsdf::OutlineCmd *cmds, const uint32_t *cmd_off, const double *scale, uint32_t n_glyphs,
@@ -85,10 +89,15 @@ int vgsdf_outline_plan(const vgsdf::OutlineRect *rects, uint32_t n_glyphs, int s
                        uint32_t span_budget, uint32_t tile_cap, vgsdf::GlyphDesc *descs, uint2 *tiles, vgsdf::PlanHeader *hdr,
                        const uint32_t *error_flag, unsigned long long seg_cap, unsigned long long out_cap, uint32_t launch_spans,
                        const uint32_t *pbf_pre /* NULL: bitmaps packed back to back */, const uint8_t *pbf_fix,
-                       unsigned long long *pbf_at /* [n_glyphs] positions of the bitmaps in the arena */, hipStream_t stream);
+                       unsigned long long *pbf_at /* [n_glyphs] positions of the bitmaps in the arena */,
+                       uint32_t *next_flag /* may be NULL: a word the kernel zeroes (the next submission's error word) */, hipStream_t stream);
 int vgsdf_outline_emit_segments(const vgsdf::OutlineCmd *cmds, uint32_t n_cmds, const uint8_t *cmd_open, const double *scale,
                                 const double *shift_x,
                                 const uint32_t *pt_local, const vgsdf::RingRec *rings, const uint32_t *cmd_ring,
                                 const vgsdf::GlyphDesc *descs, const vgsdf::PlanHeader *hdr, unsigned long long seg_cap,
-                                double *seg /* records {sx, sy, ex, ey} */, const unsigned long long *cmd_mask, hipStream_t stream);
+                                double *seg /* records {sx, sy, ex, ey} */, const unsigned long long *cmd_mask,
+                                // n_box_glyphs = n_glyphs: the first workgroups of the grid also fill the raster's chunk-box table
+                                // (sdf_kernels.h, vgsdf_chunk_box_bytes) from the commands' boxes — boxes that CONTAIN the exact ones of
+                                // vgsdf_launch_chunk_boxes; 0: no boxes (cmd_off / cmd_box / boxes unused)
+                                uint32_t n_box_glyphs, const uint32_t *cmd_off, const void *cmd_box, void *boxes, hipStream_t stream);
 }

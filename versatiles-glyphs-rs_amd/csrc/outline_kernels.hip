@@ -773,13 +773,15 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 		const uint32_t k = valid ? cmds[c].kind : 0xFFu;
 		const bool open = valid && (cmd_open[c] & 1);
 		const bool starts = k == CMD_MOVE || (k == CMD_LINE && !open);
-		const bool ends = open && (k == CMD_MOVE || k == CMD_CLOSE);
+		const bool ends_cmd = open && (k == CMD_MOVE || k == CMD_CLOSE);
 		const bool have_after = k == CMD_MOVE || k == CMD_LINE || (valid && k != CMD_CLOSE && open);
 		// nearest ring start at or before this lane (strictly before for the ring this command ends)
 		const unsigned long long sb = __ballot(starts);
 		const unsigned long long below = sb & ((1ull << lane) - 1ull);
 		const uint32_t start_before = below ? base + (uint32_t)(63 - __builtin_clzll(below)) : last_start;
 		const uint32_t start_here = starts ? c : start_before;
+		// (an "open" ring has a command that opened it — context bytes that say otherwise would index ring 0xFFFFFFFF)
+		const bool ends = ends_cmd && start_before != 0xFFFFFFFFu;
 		if (valid) {
 			cmd_ring[c] = have_after ? start_here : 0xFFFFFFFFu;
 			if (in_lds)
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(64) void outline_rings(const OutlineCmd *__restrict
 		const uint32_t n_valid = min(64u, c1 - base);
 		open_after = (ha >> (n_valid - 1)) & 1ull;
 	}
-	if (open_after && lane == 0) { // into_rings: the ring still open at the end of the glyph
+	if (open_after && lane == 0 && last_start != 0xFFFFFFFFu) { // into_rings: the ring still open at the end of the glyph
 		RingRec rec = ring_rec(last_start, c1);
 		rec.seg_local = seg_base;
 		if (rec.accepted) {
@@ -968,9 +970,13 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
                                                              const uint32_t *__restrict__ error_flag, unsigned long long seg_cap,
                                                              unsigned long long out_cap, uint32_t launch_spans,
                                                              const uint32_t *__restrict__ pbf_pre, const uint8_t *__restrict__ pbf_fix,
-                                                             unsigned long long *__restrict__ pbf_at)
+                                                             unsigned long long *__restrict__ pbf_at, uint32_t *__restrict__ next_flag)
 {
 	__shared__ unsigned long long s_wave[kPlanThreads / 64 + 1];
+	// the error word of the NEXT submission of this context (the two alternate): zeroed here, behind everything that could
+	// still raise the previous use of that word, instead of a memset launch in front of every submission
+	if (threadIdx.x == 0 && next_flag != nullptr)
+		next_flag[0] = 0;
 	__shared__ uint32_t s_hist[2][kPlanBuckets]; // spans per (class, bucket); then the bucket's write cursor
 	__shared__ unsigned long long s_carry[2];
 	const uint32_t tid = threadIdx.x;
@@ -1166,6 +1172,99 @@ __global__ __launch_bounds__(kPlanThreads) void outline_plan(const OutlineRect *
 }
 
 // ---------------------------------------------------------------------------------------
+// chunk boxes from the commands' boxes (one wave per glyph of more than two chunks).  The raster skips a chunk of 256
+// segments whose box is far from a span (sdf_span_kernel.inc); sdf_chunk_boxes takes those boxes from the segments, i.e.
+// behind the second flattening pass, on the path every bitmap waits for.  Everything needed for a box that CONTAINS the
+// chunk's segments is known once the plan has run: the count pass stored the box of the points every command appends, the
+// ring pass where those points sit in their ring, the plan where the glyph's segments start.  Point q of an accepted ring
+// (ring-local) starts segment q and ends segment q - 1; with the appended copy of point 0 (Ring::close, ring.rs:53-63)
+// point 0 also ends the ring's last segment.  So a command whose points are [qa, qb) touches the ring's segments
+// max(qa - 1, 0) .. min(qb - 1, last), plus the last one if it holds point 0 of a closed-by-append ring: its box goes into
+// the chunks of those segments.  Both end points of every segment are covered that way, so the union is a superset of the
+// exact box (by a command's extent, a few dozen points): chunks are skipped a little less often, never wrongly.  Boxes are
+// pushed through the glyph's transform exactly as the ring pass does (monotone for scale > 0; for any other scale the count
+// pass took them on the transformed points), then made relative to (x0, y0) and rounded to f32 like sdf_chunk_boxes' — the
+// raster's pad covers the rounding.  The first `n_box_glyphs` workgroups of outline_emit_segments' grid do this, one glyph each,
+// beside the second flattening pass: no launch and no dependency of its own (a separate stream for it cost what it saved).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kBoxLdsChunks = 256; // glyphs of more chunks (> 65 536 segments) get boxes that contain everything
+
+__device__ __forceinline__ void chunk_boxes_of_glyph(uint32_t g, uint32_t lane, uint32_t (*s_key)[kBoxLdsChunks] /* [4]: min x, min y, max x, max y
+                                                     as order-preserving keys of the f32 values */,
+                                                     const uint32_t *__restrict__ cmd_off, const double *__restrict__ scale,
+                                                     const double *__restrict__ shift_x, const uint32_t *__restrict__ pt_local,
+                                                     const RingRec *__restrict__ rings, const uint32_t *__restrict__ cmd_ring,
+                                                     const double4 *__restrict__ cmd_box, const GlyphDesc *__restrict__ descs,
+                                                     float4 *__restrict__ boxes)
+{
+	const GlyphDesc d = descs[g];
+	if (d.n_seg <= 2u * 256u) // (the raster asks for boxes only when a glyph has more than two chunks)
+		return;
+	const uint32_t n_chunks = (d.n_seg + 255u) >> 8;
+	const float inf = __builtin_inff();
+	if (n_chunks > kBoxLdsChunks) {
+		for (uint32_t c = lane; c < n_chunks; c += 64u)
+			boxes[chunk_box_index(d.seg_off, g, c)] = make_float4(-inf, -inf, inf, inf);
+		return;
+	}
+	auto key = [](float v) { // f32 -> u32 with the same order
+		const uint32_t b = __float_as_uint(v);
+		return (b >> 31) ? ~b : (b | 0x80000000u);
+	};
+	auto unkey = [](uint32_t k) { return __uint_as_float((k >> 31) ? (k & 0x7FFFFFFFu) : ~k); };
+	for (uint32_t c = lane; c < n_chunks; c += 64u) {
+		s_key[0][c] = s_key[1][c] = key(inf);
+		s_key[2][c] = s_key[3][c] = key(-inf);
+	}
+	__syncthreads();
+	const uint32_t c0 = cmd_off[g], c1 = cmd_off[g + 1];
+	const double sc = scale[g], dx = shift_x[g];
+	const bool raw_boxes = sc > 0.0 && sc < __builtin_huge_val(); // (as the count and ring passes decide)
+	for (uint32_t c = c0 + lane; c < c1; c += 64u) {
+		const uint32_t rs = cmd_ring[c];
+		if (rs == 0xFFFFFFFFu)
+			continue;
+		const RingRec r = rings[rs];
+		const uint32_t a = pt_local[c + g], b = pt_local[c + 1 + g]; // the command's points inside the glyph
+		if (!r.accepted || b <= a || a < r.pt_first)
+			continue;
+		const uint32_t last = r.pt_count + r.append - 2u; // last segment of the ring (accepted: pt_count + append >= 4)
+		const uint32_t qa = a - r.pt_first, qb = b - r.pt_first;
+		const uint32_t s_lo = qa ? qa - 1u : 0u, s_hi = min(qb - 1u, last);
+		double4 bx = cmd_box[c];
+		if (raw_boxes) {
+			bx.x *= sc, bx.y *= sc, bx.z *= sc, bx.w *= sc; // point.rs:96-99
+			bx.x += dx, bx.z += dx;                         // point.rs:83-86
+			bx.y += 0.0, bx.w += 0.0;
+		}
+		float x0 = (float)(bx.x - (double)d.x0), y0 = (float)(bx.y - (double)d.y0);
+		float x1 = (float)(bx.z - (double)d.x0), y1 = (float)(bx.w - (double)d.y0);
+		if (!(fabsf(x0) < 3.0e38f) || !(fabsf(y0) < 3.0e38f) || !(fabsf(x1) < 3.0e38f) || !(fabsf(y1) < 3.0e38f))
+			x0 = y0 = -inf, x1 = y1 = inf; // non-finite: the chunks it touches are never skipped
+		auto put = [&](uint32_t s_first, uint32_t s_last) {
+			const uint32_t k_lo = (r.seg_local + s_first) >> 8, k_hi = min((r.seg_local + s_last) >> 8, n_chunks - 1u);
+			for (uint32_t k = k_lo; k <= k_hi; k++) {
+				atomicMin(&s_key[0][k], key(x0));
+				atomicMin(&s_key[1][k], key(y0));
+				atomicMax(&s_key[2][k], key(x1));
+				atomicMax(&s_key[3][k], key(y1));
+			}
+		};
+		if (s_lo <= s_hi)
+			put(s_lo, s_hi);
+		if (qa == 0u && r.append)
+			put(last, last); // point 0 ends the segment Ring::close appended
+	}
+	__syncthreads();
+	for (uint32_t c = lane; c < n_chunks; c += 64u) {
+		float4 o = make_float4(unkey(s_key[0][c]), unkey(s_key[1][c]), unkey(s_key[2][c]), unkey(s_key[3][c]));
+		if (!(o.x <= o.z) || !(o.y <= o.w)) // nothing arrived (cannot happen: every segment has end points): never skip
+			o = make_float4(-inf, -inf, inf, inf);
+		boxes[chunk_box_index(d.seg_off, g, c)] = o;
+	}
+}
+
+// ---------------------------------------------------------------------------------------
 // emit: thread per command — the second flattening pass.  Point i of a ring of n points is the start of segment i
 // (i <= n - 2, or i == n - 1 when Ring::close appended the first point again) and the end of segment i - 1; with
 // the appended point, point 0 also ends segment n - 1 (Rings::get_segments, rings.rs:75-81) — written straight
@@ -1183,10 +1282,13 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
                                                                          const GlyphDesc *__restrict__ descs,
                                                                          const PlanHeader *__restrict__ hdr,
                                                                          unsigned long long seg_cap, double2 *__restrict__ seg,
-                                                                         const unsigned long long *__restrict__ cmd_mask)
+                                                                         const unsigned long long *__restrict__ cmd_mask,
+                                                                         uint32_t n_box_glyphs, const uint32_t *__restrict__ cmd_off,
+                                                                         const double4 *__restrict__ cmd_box, float4 *__restrict__ boxes)
 {
 	__shared__ double s_stack[kSerialStackDoubles];
 	__shared__ WaveQuads s_w;
+	__shared__ uint32_t s_key[4][kBoxLdsChunks];
 	// per command, for the lanes that place its points: first record of its ring, index of its first point inside
 	// the ring, the ring's point count and closing flag, the glyph's transform
 	__shared__ unsigned long long s_seg0[64];
@@ -1195,7 +1297,13 @@ __global__ __launch_bounds__(kFlattenThreads) void outline_emit_segments(const O
 	if (hdr->error || hdr->n_segments > seg_cap) // nothing may be written: the host grows the arrays and launches again
 		return;
 	const uint32_t lane = threadIdx.x;
-	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	// the first n_box_glyphs workgroups: chunk boxes of one glyph each (see chunk_boxes_of_glyph), first so that the longest
+	// of them are under way when the flattening workgroups fill the chip
+	if (blockIdx.x < n_box_glyphs) {
+		chunk_boxes_of_glyph(blockIdx.x, lane, s_key, cmd_off, scale, shift_x, pt_local, rings, cmd_ring, cmd_box, descs, boxes);
+		return;
+	}
+	const uint32_t c = (blockIdx.x - n_box_glyphs) * blockDim.x + threadIdx.x;
 	bool active = c < n_cmds;
 	uint32_t rcmd = 0xFFFFFFFFu;
 	RingRec r;
@@ -1352,9 +1460,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v)
 }
 
 // max_points / max_bytes: what the launch's LDS was sized for (the batch's largest cmd_cap bounds its largest point count)
+// cmd_open (may be NULL): the context pass's result for these commands, written here as well — whether the ring is non-empty in
+// front of a command follows from the contour rules alone: every contour of a part begins on an empty ring (the contour
+// in front of it, or the filler behind the previous part, ended with close()), its move_to opens the ring and everything
+// behind it up to its close() finds it open.  (Bit 1 of the context byte — a glyph whose scale is not positive and finite —
+// is the caller's to rule out: the host passes cmd_open only when every scale of the batch is.)
 __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ parts, uint32_t n_parts, const uint8_t *__restrict__ bytes,
                                                   OutlineCmd *__restrict__ cmds, uint32_t *__restrict__ error_flag, uint32_t max_points,
-                                                  uint32_t max_bytes)
+                                                  uint32_t max_bytes, uint8_t *__restrict__ cmd_open)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
 	uint8_t *const body = s_dyn;                                              // [max_bytes] the part's bytes (a multiple of 4)
@@ -1377,6 +1490,7 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 		__builtin_amdgcn_wave_barrier();
 	}
 	OutlineCmd *out = cmds + pt.cmd_at;
+	uint8_t *out_open = cmd_open ? cmd_open + pt.cmd_at : nullptr;
 	auto u16 = [&](uint32_t at) { return (uint32_t)((body[at] << 8) | body[at + 1]); };
 	auto close_cmd = [] {
 		OutlineCmd o;
@@ -1393,6 +1507,7 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 		n_points = last_end + 1u;
 	}
 	uint32_t written = 0;
+	bool open_end = false; // the part's last contour ran out of points (end points beyond the entry's points): no close() of its own
 	if (ok && n_points > 1u)
 		ok = n_points <= max_points && (unsigned long long)n_points + 2ull * nc <= cap;
 	if (ok && n_points > 1u) {
@@ -1563,12 +1678,15 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 				}
 				uint32_t tn;
 				uint32_t at = written + wave_exclusive_sum(n, tn);
+				bool ring_open = false; // in front of the command being emitted (set below, per command)
 				auto emit = [&](uint32_t kind, float x1, float y1, float x, float y) {
 					if (at < cap) {
 						OutlineCmd o;
 						o.x1 = x1, o.y1 = y1, o.x2 = 0.0f, o.y2 = 0.0f, o.x = x, o.y = y;
 						o.kind = kind;
 						out[at] = o;
+						if (out_open)
+							out_open[at] = ring_open ? 1 : 0;
 					}
 					at++;
 				};
@@ -1594,7 +1712,8 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 					// the contour's start point: its first point when that lies on the curve, else the second, else their middle
 					const float stx = on0 ? x0 : (on1 ? x1 : x0 + 0.5f * (x1 - x0));
 					const float sty = on0 ? y0 : (on1 ? y1 : y0 + 0.5f * (y1 - y0));
-					// Builder::push_point
+					// Builder::push_point (the contour's move_to finds the ring empty, whatever follows finds it open)
+					ring_open = !(i == 0u || (i == 1u && !on0));
 					if (i == 0u) {
 						if (on0)
 							move(fx, fy);
@@ -1610,6 +1729,7 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 						line(fx, fy);
 					}
 					if (last_pt) { // Builder::finish
+						ring_open = has_start; // (a contour of one off-curve point emitted no move_to: its close() meets an empty ring)
 						if (has_lead && pend) {
 							quad(fx, fy, fx + 0.5f * (x0 - fx), fy + 0.5f * (y0 - fy));
 							pend = false;
@@ -1624,24 +1744,62 @@ __global__ __launch_bounds__(64) void glyf_decode(const GlyfPart *__restrict__ p
 					}
 				}
 				written += tn;
+				// the entry's very last point: when it does not end its contour (points that ran out inside a contour leave it
+				// unclosed, ttf-parser: no finish()), the ring is still open behind the part's last callback
+				if (base + 64u >= n_points)
+					open_end = __ballot(in && p == n_points - 1u && !last_pt && has_start) != 0;
 			}
 		}
+	}
+	if (ok && open_end && out_open && written >= cap) {
+		ok = false; // (no filler slot to close the ring in: the per-part context rule cannot say what the next part meets)
+		open_end = false;
 	}
 	if (!ok) {
 		if (lane == 0)
 			atomicOr(error_flag, 16u);
 		written = 0;
+		open_end = false;
 	}
-	for (uint32_t k = written + lane; k < cap; k += 64u)
+	// filler: close() on the empty ring does nothing (ring_builder.rs:33-38) — except the first one behind an unclosed
+	// contour, which finds the ring open and ends it, as the context pass would note
+	for (uint32_t k = written + lane; k < cap; k += 64u) {
 		out[k] = close_cmd();
+		if (out_open)
+			out_open[k] = (open_end && k == written) ? 1 : 0;
+	}
+}
+
+
+// The upload of a submission whose input sits in ONE page-locked, device-mapped block: 16 bytes per thread, every load of
+// the block in flight at once — one PCIe round trip plus the bytes, without the copy engine's hand-over in front of the
+// first kernel (hipMemcpyAsync: 16.5 us for the 200 KB of a font + 8.7 us until the next kernel starts).
+__global__ __launch_bounds__(256) void copy_in(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16, const uint8_t *__restrict__ src_tail,
+                                               uint8_t *__restrict__ dst_tail, uint32_t n_tail)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n16)
+		dst[i] = src[i];
+	if (i < n_tail)
+		dst_tail[i] = src_tail[i];
 }
 
 } // namespace vgsdf
 
 using namespace vgsdf;
 
+extern "C" int vgsdf_copy_in(const void *src_mapped, void *dst, size_t bytes, hipStream_t stream)
+{
+	if (bytes == 0)
+		return 0;
+	const uint32_t n16 = (uint32_t)(bytes / 16), n_tail = (uint32_t)(bytes % 16);
+	hipLaunchKernelGGL(copy_in, dim3((std::max(n16, 1u) + 255u) / 256u), dim3(256), 0, stream, (const uint4 *)src_mapped, (uint4 *)dst, n16,
+	                   (const uint8_t *)src_mapped + 16 * (size_t)n16, (uint8_t *)dst + 16 * (size_t)n16, n_tail);
+	return (int)hipGetLastError();
+}
+
 extern "C" int vgsdf_glyf_decode(const void *parts, uint32_t n_parts, const uint8_t *bytes, OutlineCmd *cmds, uint32_t *error_flag,
-                                 uint32_t max_cmd_cap, uint32_t max_byte_len, hipStream_t stream)
+                                 uint32_t max_cmd_cap, uint32_t max_byte_len, uint8_t *cmd_open, hipStream_t stream)
 {
 	if (n_parts == 0)
 		return 0;
@@ -1651,7 +1809,7 @@ extern "C" int vgsdf_glyf_decode(const void *parts, uint32_t n_parts, const uint
 	const uint32_t max_bytes = std::min((std::max(max_byte_len, 64u) + 15u) & ~15u, kGlyfMaxBytes);
 	const size_t lds = (size_t)max_bytes + 4 * (size_t)max_points + 4 * (size_t)((max_points + 31u) / 32u) + max_points;
 	hipLaunchKernelGGL(glyf_decode, dim3(n_parts), dim3(64), lds, stream, (const GlyfPart *)parts, n_parts, bytes, cmds, error_flag, max_points,
-	                   max_bytes);
+	                   max_bytes, cmd_open);
 	return (int)hipGetLastError();
 }
 
@@ -1703,14 +1861,14 @@ extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, i
                                   uint32_t span_budget, uint32_t tile_cap, GlyphDesc *descs, uint2 *tiles, PlanHeader *hdr,
                                   const uint32_t *error_flag, unsigned long long seg_cap, unsigned long long out_cap,
                                   uint32_t launch_spans, const uint32_t *pbf_pre, const uint8_t *pbf_fix,
-                                  unsigned long long *pbf_at, hipStream_t stream)
+                                  unsigned long long *pbf_at, uint32_t *next_flag, hipStream_t stream)
 {
 	if (pbf_fix != nullptr && n_glyphs <= 4u * kPlanThreads)
 		hipLaunchKernelGGL((outline_plan<4, true>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
-		                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at);
+		                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at, next_flag);
 	else
 	hipLaunchKernelGGL((outline_plan<8, false>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
-	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at);
+	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at, next_flag);
 	return (int)hipGetLastError();
 }
 
@@ -1718,11 +1876,13 @@ extern "C" int vgsdf_outline_emit_segments(const OutlineCmd *cmds, uint32_t n_cm
                                            const double *shift_x,
                                            const uint32_t *pt_local, const RingRec *rings, const uint32_t *cmd_ring,
                                            const GlyphDesc *descs, const PlanHeader *hdr, unsigned long long seg_cap, double *seg,
-                                           const unsigned long long *cmd_mask, hipStream_t stream)
+                                           const unsigned long long *cmd_mask, uint32_t n_box_glyphs, const uint32_t *cmd_off,
+                                           const void *cmd_box, void *boxes, hipStream_t stream)
 {
 	if (n_cmds == 0)
 		return 0;
-	hipLaunchKernelGGL(outline_emit_segments, dim3((n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0, stream,
-	                   cmds, n_cmds, cmd_open, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg, cmd_mask);
+	hipLaunchKernelGGL(outline_emit_segments, dim3(n_box_glyphs + (n_cmds + kFlattenThreads - 1) / kFlattenThreads), dim3(kFlattenThreads), 0,
+	                   stream, cmds, n_cmds, cmd_open, scale, shift_x, pt_local, rings, cmd_ring, descs, hdr, seg_cap, (double2 *)seg, cmd_mask,
+	                   n_box_glyphs, cmd_off, (const double4 *)cmd_box, (float4 *)boxes);
 	return (int)hipGetLastError();
 }

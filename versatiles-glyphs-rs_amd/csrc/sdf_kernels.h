@@ -18,6 +18,10 @@ struct GlyphDesc {
 };
 static_assert(sizeof(GlyphDesc) == 32, "GlyphDesc must stay 32 bytes");
 
+// Index of the box of chunk c (256 segments) of glyph g in the chunk-box table: (seg_off[g] >> 8) + g + c — unique for a
+// monotone seg_off, so no offset table is needed; the table has (total segments >> 8) + n_glyphs + 1 entries.
+__device__ __forceinline__ uint32_t chunk_box_index(uint32_t seg_off, uint32_t glyph, uint32_t c) { return (seg_off >> 8) + glyph + c; }
+
 } // namespace vgsdf
 
 // largest rows*(w+1) a tile of the filtered kernel may need (winding histogram in LDS)

@@ -202,11 +202,6 @@ namespace vgsdf {
 // Index of chunk c of glyph g: (seg_off[g] >> 8) + g + c — unique for a monotone seg_off, so no
 // offset table is needed; the table has (total segments >> 8) + n_glyphs + 1 entries.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t chunk_box_index(uint32_t seg_off, uint32_t glyph, uint32_t c)
-{
-	return (seg_off >> 8) + glyph + c;
-}
-
 __global__ __launch_bounds__(256) void sdf_chunk_boxes(const GlyphDesc *__restrict__ glyphs, uint32_t n_glyphs,
                                                       const double *__restrict__ seg_sx,
                                                       const double *__restrict__ seg_sy,

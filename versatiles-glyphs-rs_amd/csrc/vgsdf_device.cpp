@@ -155,6 +155,12 @@ struct FrontEnd {
 	DevBuf h_rects, h_stage; // pinned
 	size_t seg_cap = 0, tile_cap = 0; // elements the segment arrays / the work list hold
 	uint32_t last_spans = 0;          // work-list length of the previous batch (grid guess of the one-submission form)
+	// error words of the submissions: two 16-byte slots used alternately; the plan kernel of a submission zeroes the other
+	// slot for its successor (no memset launch per submission).  flags_clean: both slots are known to be in that state
+	uint32_t flag_slot = 0;
+	bool flags_clean = false;
+	uint32_t *flag_word() const { return (uint32_t *)((uint8_t *)flag.p + 16 * (size_t)flag_slot); }
+	uint32_t *next_flag_word() const { return (uint32_t *)((uint8_t *)flag.p + 16 * (size_t)(flag_slot ^ 1u)); }
 	FePending pend;
 	uint32_t n_glyphs = 0, n_cmds = 0, n_segs = 0;
 	uint64_t out_bytes = 0;
@@ -835,18 +841,24 @@ int fe_launch_plan(vgsdf_ctx *ctx, FrontEnd &fe, uint32_t spans_launched)
 	const FeDev d = fe_dev(fe);
 	return vgsdf_outline_plan(d.rects, p.n, p.span ? 1 : 0, (uint32_t)vgsdf_filtered_delta_cap(), p.span_max, p.span_budget,
 	                          (uint32_t)std::min<size_t>(fe.tile_cap, 0x7FFFFFFFu), d.descs, (uint2 *)fe.tiles.p, d.hdr,
-	                          (const uint32_t *)fe.flag.p, (unsigned long long)fe.seg_cap, (unsigned long long)p.spec_cap,
+	                          fe.flag_word(), (unsigned long long)fe.seg_cap, (unsigned long long)p.spec_cap,
 	                          spans_launched, p.d_pbf_pre, p.d_pbf_fix,
-	                          p.d_pbf_fix ? (unsigned long long *)((uint8_t *)fe.rects_hdr.p + p.at_off) : nullptr, ctx->stream);
+	                          p.d_pbf_fix ? (unsigned long long *)((uint8_t *)fe.rects_hdr.p + p.at_off) : nullptr, fe.next_flag_word(), ctx->stream);
 }
+// The second flattening pass and the raster's chunk boxes.  Boxes: by default the first workgroups of the pass's own grid take
+// them from the commands' boxes (outline_kernels.hip, chunk_boxes_of_glyph: supersets of the exact boxes, no launch of their
+// own); VGSDF_CMD_BOXES=0 (measurement switch): from the segments, by sdf_chunk_boxes behind the pass
 int fe_launch_emit(vgsdf_ctx *ctx, FrontEnd &fe)
 {
 	const FePending &p = fe.pend;
 	const FeDev d = fe_dev(fe);
+	static const char *cb_env = std::getenv("VGSDF_CMD_BOXES");
+	const bool cmd_boxes = p.span && !(cb_env && cb_env[0] == '0');
 	int e = vgsdf_outline_emit_segments(d.cmds, p.n_cmds, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, (const uint32_t *)fe.pt_local.p,
 	                                    (const vgsdf::RingRec *)fe.rings.p, (const uint32_t *)fe.cmd_ring.p, d.descs, d.hdr,
-	                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, (const unsigned long long *)fe.cmd_mask.p, ctx->stream);
-	if (e == 0 && p.span)
+	                                    (unsigned long long)fe.seg_cap, (double *)fe.seg.p, (const unsigned long long *)fe.cmd_mask.p,
+	                                    cmd_boxes ? p.n : 0u, d.cmd_off, fe.cmd_box.p, fe.boxes.p, ctx->stream);
+	if (e == 0 && p.span && !cmd_boxes)
 		e = vgsdf_launch_chunk_boxes(d.descs, p.n, (const double *)fe.seg.p, (const double *)fe.seg.p + 1, (const double *)fe.seg.p + 2,
 		                             (const double *)fe.seg.p + 3, 4, fe.boxes.p, d.hdr, (unsigned long long)fe.seg_cap, ctx->stream);
 	return e;
@@ -923,6 +935,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		return VGSDF_E_ARG;
 	}
 	uint32_t glyf_max_cap = 0, glyf_max_len = 0;
+	bool parts_inside_glyphs = true; // every part's slots lie inside ONE glyph's range (what a sound caller sends)
 	if (in->glyf) {
 		// the parts tile the command slots in order, and their bytes lie inside `bytes` (what the bytes SAY is checked on
 		// the device, entry by entry)
@@ -931,8 +944,12 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 			return VGSDF_E_ARG;
 		}
 		uint64_t slots = 0;
+		uint32_t gi = 0;
 		for (uint32_t i = 0; i < in->n_parts; i++) {
 			const vgsdf_glyf_part &pt = in->parts[i];
+			while (gi < n && in->cmd_off[gi + 1] <= pt.cmd_at)
+				gi++;
+			parts_inside_glyphs = parts_inside_glyphs && gi < n && pt.cmd_at >= in->cmd_off[gi] && (uint64_t)pt.cmd_at + pt.cmd_cap <= in->cmd_off[gi + 1];
 			glyf_max_cap = std::max(glyf_max_cap, pt.cmd_cap);
 			glyf_max_len = std::max(glyf_max_len, pt.byte_len);
 			if (pt.cmd_at != slots || (pt.byte_off & 3u) || pt.byte_off > in->n_bytes || pt.byte_len > in->n_bytes - pt.byte_off ||
@@ -1043,7 +1060,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	FE_TRY(fe.rects_hdr.ensure(p.rh_bytes));
 	FE_TRY(fe.h_rects.ensure(p.rh_bytes));
 	FE_TRY(fe.descs.ensure(sizeof(vgsdf::GlyphDesc) * (size_t)n + 16));
-	FE_TRY(fe.flag.ensure(16));
+	FE_TRY(fe.flag.ensure(32));
 	// capacities of what only the device knows the size of: the work list and the segment arrays.  Guessed from
 	// the input (and kept from earlier batches); the plan / emit kernels write nothing past them and the totals
 	// that come back with the rects say whether a second launch is needed.
@@ -1052,13 +1069,27 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 
 	if (std::getenv("VGSDF_TRACE") != nullptr)
 		FE_TRY(hipEventRecord(ctx->ev0, st));
+	// a single page-locked block that the device can address is uploaded by a kernel (outline_kernels.hip, copy_in) instead of
+	// the copy engine; VGSDF_COPY_KERNEL=0: measurement switch
+	static const char *ck_env = std::getenv("VGSDF_COPY_KERNEL");
+	const void *hb_mapped = nullptr;
+	if ((gblob || blob) && !(ck_env && ck_env[0] == '0') && ((uintptr_t)hb & 15u) == 0)
+		hb_mapped = pinned_device_ptr(const_cast<uint8_t *>(hb), gblob ? gl_total : blob_bytes);
+	// error word of this submission (FrontEnd::flag_slot)
+	if (!fe.flags_clean)
+		FE_TRY(hipMemsetAsync(fe.flag.p, 0, 32, st));
+	fe.flags_clean = false; // (until everything below is enqueued: its plan kernel zeroes the other slot)
+	fe.flag_slot ^= 1u;
+	uint32_t *const flagw = fe.flag_word();
 	const uint8_t *d_kinds = nullptr;
 	const float *d_coords = nullptr;
 	const uint8_t *d_parts = nullptr, *d_bytes = nullptr;
 	if (in->glyf) {
 		// (device layout = the single-block layout, whether the arrays arrive as one block or one by one)
 		uint8_t *dm = (uint8_t *)fe.meta.p;
-		if (gblob) {
+		if (gblob && hb_mapped) {
+			FE_KERNEL(vgsdf_copy_in(hb_mapped, dm, gl_total, st));
+		} else if (gblob) {
 			FE_TRY(hipMemcpyAsync(dm, hb, gl_total, hipMemcpyHostToDevice, st));
 		} else {
 			FE_TRY(hipMemcpyAsync(dm + meta_scale, in->scale, 8 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1080,7 +1111,10 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 			p.d_pbf_fix = dm + gl_fix;
 		}
 	} else if (blob) {
-		FE_TRY(hipMemcpyAsync(fe.meta.p, hb, blob_bytes, hipMemcpyHostToDevice, st));
+		if (hb_mapped)
+			FE_KERNEL(vgsdf_copy_in(hb_mapped, fe.meta.p, blob_bytes, st));
+		else
+			FE_TRY(hipMemcpyAsync(fe.meta.p, hb, blob_bytes, hipMemcpyHostToDevice, st));
 		d_coords = (const float *)((const uint8_t *)fe.meta.p + blob_coords);
 		d_kinds = (const uint8_t *)fe.meta.p + blob_kinds;
 		if (pbf) {
@@ -1115,7 +1149,6 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		p.d_pbf_pre = (const uint32_t *)fe.pbf_in.p;
 		p.d_pbf_fix = (const uint8_t *)fe.pbf_in.p + 4 * (size_t)n;
 	}
-	FE_TRY(hipMemsetAsync(fe.flag.p, 0, 16, st));
 	const FeDev d = fe_dev(fe);
 
 	// the raster launch enqueued behind the front-end: default kernel only, destination the caller's page-locked
@@ -1132,21 +1165,32 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		const size_t guess = fe.last_spans ? (size_t)fe.last_spans + fe.last_spans / 2 + 256 : fe.tile_cap;
 		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
+	// glyf form: the decoder writes the context bytes itself (the ring state follows from the contour rules) when no glyph
+	// of the batch has an odd scale (not positive and finite: bit 1 of the context byte, which only the context pass forms)
+	// and no part straddles two glyphs (the decoder's rule is per part; the ring pass trusts the context bytes to be those of
+	// the glyph's own command sequence — a byte that says "open" in front of a glyph's first command would index a ring
+	// that does not exist)
+	bool decode_makes_context = in->glyf && parts_inside_glyphs;
+	for (uint32_t g = 0; g < n && decode_makes_context; g++)
+		decode_makes_context = in->scale[g] > 0.0 && in->scale[g] < HUGE_VAL;
+	static const char *fuse_env = std::getenv("VGSDF_FUSE_CONTEXT"); // (measurement switch)
+	if (fuse_env && fuse_env[0] == '0')
+		decode_makes_context = false;
 	if (in->glyf)
-		FE_KERNEL(vgsdf_glyf_decode(d_parts, in->n_parts, d_bytes, (vgsdf::OutlineCmd *)fe.cmds.p, (uint32_t *)fe.flag.p, glyf_max_cap,
-		                            glyf_max_len, st));
+		FE_KERNEL(vgsdf_glyf_decode(d_parts, in->n_parts, d_bytes, (vgsdf::OutlineCmd *)fe.cmds.p, flagw, glyf_max_cap, glyf_max_len,
+		                            decode_makes_context ? (uint8_t *)fe.cmd_open.p : nullptr, st));
 	if (in->packed)
 		FE_KERNEL(vgsdf_outline_context_packed(d_kinds, d_coords,
 		                                       (const uint32_t *)((const uint8_t *)fe.meta.p + meta_dat), d.cmd_off, d.scale, n,
-		                                       (vgsdf::OutlineCmd *)fe.cmds.p, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
-	else
-		FE_KERNEL(vgsdf_outline_context(d.cmds, d.cmd_off, d.scale, n, (uint8_t *)fe.cmd_open.p, (uint32_t *)fe.flag.p, st));
+		                                       (vgsdf::OutlineCmd *)fe.cmds.p, (uint8_t *)fe.cmd_open.p, flagw, st));
+	else if (!decode_makes_context)
+		FE_KERNEL(vgsdf_outline_context(d.cmds, d.cmd_off, d.scale, n, (uint8_t *)fe.cmd_open.p, flagw, st));
 	FE_KERNEL(vgsdf_outline_count(d.cmds, (const uint8_t *)fe.cmd_open.p, n_cmds, d.cmd_off, n, d.scale, d.shift,
-	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, (unsigned long long *)fe.cmd_mask.p, (uint32_t *)fe.flag.p, st));
+	                              (uint32_t *)fe.counts.p, fe.cmd_box.p, (unsigned long long *)fe.cmd_mask.p, flagw, st));
 	FE_KERNEL(vgsdf_outline_rings(d.cmds, d.cmd_off, (const uint8_t *)fe.cmd_open.p, d.scale, d.shift, n,
 	                              (const uint32_t *)fe.counts.p, (uint32_t *)fe.pt_local.p,
 	                              fe.cmd_box.p, (vgsdf::RingRec *)fe.rings.p, (uint32_t *)fe.cmd_ring.p, d.rects,
-	                              (uint32_t *)fe.flag.p, st));
+	                              flagw, st));
 	FE_KERNEL(fe_launch_plan(ctx, fe, p.launch_spans));
 	// The front-end's results (rects, totals, positions of the bitmaps) are final once the plan has run: they travel back
 	// on a stream of their own, beside the flattening and the raster instead of behind them — the host can have them a
@@ -1171,6 +1215,7 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	static const bool trace_span = std::getenv("VGSDF_TRACE") != nullptr;
 	if (trace_span)
 		FE_TRY(hipEventRecord(ctx->ev1, st));
+	fe.flags_clean = true; // the plan kernel enqueued above leaves the other slot zeroed for the next submission
 	p.active = true;
 	return VGSDF_OK;
 }
