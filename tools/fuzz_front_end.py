@@ -3,9 +3,12 @@ segments + rects) against the oracle's RingBuilder restatement: random command s
 ones ttf-parser never emits (curves on an empty ring, missing / repeated closes, cubic segments,
 degenerate and repeated points, tiny and huge coordinates).  Exits non-zero at the first difference.
 
-    python tools/fuzz_front_end.py seconds seed [curves]
+    python tools/fuzz_front_end.py seconds seed [curves|render]
 `curves`: outline-like streams of mostly cubics and quadratics whose control points stay near the chord (the depths the
-parallel flattening rounds take: 0..6), also with coordinates at the flatness threshold."""
+parallel flattening rounds take: 0..6), also with coordinates at the flatness threshold.
+`render`: the same streams at 24 .. 200 px per EM, and the BITMAPS of the whole device path (front-end + raster, with the chunk
+boxes the front-end derives from the commands' boxes: they decide which chunks a span skips) against the oracle's raster of
+the oracle's segments — outlines of several hundred to several thousand segments, where those boxes matter."""
 import sys
 import time
 from pathlib import Path
@@ -21,7 +24,8 @@ vg = load_product()
 budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-curvy = len(sys.argv) > 3 and sys.argv[3] == "curves"
+render = len(sys.argv) > 3 and sys.argv[3] == "render"
+curvy = render or (len(sys.argv) > 3 and sys.argv[3] == "curves")
 ctx = vg.SdfContext(0)
 M, L, Q, C, Z = 0, 1, 2, 3, 4
 
@@ -58,7 +62,8 @@ def curvy_stream():
                 cmds.append((C, c1[0], c1[1], c2[0], c2[1], p[0], p[1]))
             last = p
         cmds.append((Z, 0, 0, 0, 0, 0, 0))
-    return cmds, 24.0 / upem, float(rng.uniform(-0.5, 0.5))
+    px = float(rng.choice([24.0, 24.0, 60.0, 200.0])) if render else 24.0
+    return cmds, px / upem, float(rng.uniform(-0.5, 0.5))
 
 
 def stream():
@@ -93,9 +98,9 @@ def stream():
 
 
 t0 = time.time()
-n_batches = n_streams = n_segs = 0
+n_batches = n_streams = n_segs = n_px = n_big = 0
 while time.time() - t0 < budget_s:
-    sts = [stream() for _ in range(int(rng.integers(1, 60)))]
+    sts = [stream() for _ in range(int(rng.integers(1, 24 if render else 60)))]
     cmds, cmd_off = [], [0]
     for st, _, _ in sts:
         cmds += [(c[1], c[2], c[3], c[4], c[5], c[6], c[0]) for c in st]
@@ -103,6 +108,8 @@ while time.time() - t0 < budget_s:
     scale = np.array([s for _, s, _ in sts]); shift = np.array([d for _, _, d in sts])
     rects, _, _ = ctx.outlines_prepare(np.array(cmd_off, np.uint32), np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE).reshape(-1), scale, shift)
     seg_off, segs = ctx.outlines_segments()
+    bitmaps = ctx.outlines_render() if render else None
+    gl = []
     for g, (st, sc, dx) in enumerate(sts):
         want = []
         for r in O.build_rings(st):
@@ -129,7 +136,21 @@ while time.time() - t0 < budget_s:
             print(f"MISMATCH seed {seed} batch {n_batches} stream {g}: {len(got)} vs {len(want)} segments, rect {rects[g]}\n{st}", flush=True)
             sys.exit(1)
         n_segs += len(want)
+        if render and int(rects[g]["has_raster"]):
+            gl.append((want, int(rects[g]["x0"]), int(rects[g]["y0"]), int(rects[g]["w"]), int(rects[g]["h"])))
+            n_big += len(want) > 512
+    if render and gl:
+        ob = vg.make_batch(gl)
+        ref, _ = O.sdf_render_batch(ob, O.BRUTE, 16)
+        if not np.array_equal(ref, bitmaps[:len(ref)]) or len(bitmaps) != len(ref):
+            bad = np.flatnonzero(ref != bitmaps[:len(ref)])
+            print(f"BITMAP MISMATCH seed {seed} batch {n_batches}: {bad.size} bytes differ (first at {bad[:1]}), {len(bitmaps)} vs {len(ref)} bytes", flush=True)
+            np.savez(ROOT / "gpurun_out" / f"fuzz_render_fail_{seed}_{n_batches}.npz", cmds=np.array(cmds, dtype=vg.OUTLINE_CMD_DTYPE).reshape(-1),
+                     cmd_off=np.array(cmd_off, np.uint32), scale=scale, shift=shift)
+            sys.exit(1)
+        n_px += len(ref)
     n_batches += 1; n_streams += len(sts)
     if n_batches % 50 == 0:
         print(f"[{time.time() - t0:6.0f} s] {n_batches} batches, {n_streams} streams, {n_segs / 1e6:.2f} M segments: all equal", flush=True)
-print(f"done: {n_batches} batches, {n_streams} command streams, {n_segs / 1e6:.2f} M segments, 0 differences (seed {seed})", flush=True)
+print(f"done: {n_batches} batches, {n_streams} command streams, {n_segs / 1e6:.2f} M segments, 0 differences (seed {seed})" +
+      (f"; bitmaps of the whole device path: {n_px / 1e6:.1f} Mpx, {n_big} outlines of more than 512 segments, 0 differing bytes" if render else ""), flush=True)

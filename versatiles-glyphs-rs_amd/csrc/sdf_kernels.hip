@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TPB) void sdf_tiles_brute(const GlyphDesc *__restri
 
 // ---------------------------------------------------------------------------------------
 // Shared pieces of the filtered kernels (the default kernel at the end of this file, and the earlier
-// generations kept in dev/sdf_retired.inc for development builds).
+// generations kept in tools/experiments/sdf_retired.inc for development builds).
 // ---------------------------------------------------------------------------------------
 constexpr int FCHUNK = 256;      // segments per LDS stage: 20 B filter record + 32 B exact end points each
 constexpr int DELTA_CAP = 2048;  // winding histogram cells per span: rows * (w + 1)
@@ -188,7 +188,7 @@ __device__ __forceinline__ float sc_filter(float rpx, float rpy, float vx, float
 
 #ifdef VGSDF_DEV_VARIANTS
 } // namespace vgsdf
-#include "dev/sdf_retired.inc" // earlier kernel generations (A/B measurements, development builds only)
+#include "sdf_retired.inc" // tools/experiments/: earlier kernel generations (A/B measurements, `make dev` only: -I../tools/experiments)
 namespace vgsdf {
 #endif
 
