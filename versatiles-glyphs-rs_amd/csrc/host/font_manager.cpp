@@ -1761,11 +1761,25 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		g0 = g1;
 	}
 	bool in_flight[2] = {false, false};
+	// VG_TRACE_PHASES=1 (measurement switch): the calling thread's time line of the run, one line per group on stderr
+	static const bool trace_ph = std::getenv("VG_TRACE_PHASES") != nullptr;
+	struct Mark {
+		const char *what;
+		size_t k;
+		double t;
+	};
+	std::vector<Mark> marks;
+	auto mark = [&](const char *what, size_t k) {
+		if (trace_ph)
+			marks.push_back(Mark{what, k, now_s()});
+	};
 	auto submit = [&](size_t k) {
 		FeGroup &G = fe_group_[k & 1];
 		G.g0 = groups[k].first;
 		G.g1 = groups[k].second;
+		mark("record+pack >", k);
 		fe_record(tasks, G);
+		mark("submit >", k);
 		const double t = now_s();
 		if (G.n_jobs) {
 			if (G.m.glyf) {
@@ -1776,10 +1790,12 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 			in_flight[k & 1] = true;
 		}
 		timings_.device_s += now_s() - t;
+		mark("submitted", k);
 	};
 	auto collect = [&](size_t k) {
 		FeGroup &G = fe_group_[k & 1];
 		double t = now_s();
+		mark("pieces >", k);
 		G.rects.clear();
 		G.out_bytes = G.n_segs = 0;
 		// in-place assembly: the rects come back right behind the plan kernel, a good 100 us before the bitmaps — the
@@ -1788,13 +1804,16 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		if (G.in_place && G.n_jobs)
 			fe_prepare_pieces(tasks, G);
 		t = now_s();
+		mark("peek >", k);
 		if (in_flight[k & 1] && G.in_place && G.n_jobs) {
 			early = renderer.peek_outlines((int)(k & 1), G.rects, G.out_bytes, G.n_jobs, &G.pbf_at);
 			timings_.device_s += now_s() - t;
+			mark("assemble >", k);
 			if (early)
 				fe_assemble(tasks, G);
 			t = now_s();
 		}
+		mark("wait >", k);
 		if (in_flight[k & 1]) {
 			in_flight[k & 1] = false;
 			try {
@@ -1818,6 +1837,7 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 			}
 		}
 		timings_.device_s += now_s() - t;
+		mark("write >", k);
 		if (G.in_place && G.n_jobs) {
 			if (!early)
 				fe_assemble(tasks, G);
@@ -1825,6 +1845,7 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		} else {
 			fe_encode_write(tasks, G, writer);
 		}
+		mark("done", k);
 	};
 	try {
 		for (size_t k = 0; k < groups.size(); k++) {
@@ -1848,6 +1869,17 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 		throw;
 	}
 	timings_.total_s = now_s() - t_start;
+	if (trace_ph) {
+		std::string line = "[phases] " + std::to_string(groups.size()) + " groups, " + std::to_string(total_glyphs) + " glyphs:";
+		char buf[96];
+		for (const Mark &mk : marks) {
+			std::snprintf(buf, sizeof buf, " | %s g%zu @%.0f", mk.what, mk.k, (mk.t - t_start) * 1e6);
+			line += buf;
+		}
+		std::snprintf(buf, sizeof buf, " | end @%.0f us\n", timings_.total_s * 1e6);
+		line += buf;
+		std::fputs(line.c_str(), stderr);
+	}
 }
 
 void FontManager::run_tasks(std::vector<Todo> &tasks, Writer &writer, const Renderer &renderer)
