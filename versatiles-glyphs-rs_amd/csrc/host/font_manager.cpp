@@ -1375,6 +1375,11 @@ bool FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 			if (const FontFileEntry *f = blk.glyphs[ci])
 				Renderer::record_parts(f->face(), blk.start_index + ci, w.plocal);
 		s.job1 = (uint32_t)w.plocal.jobs.size();
+		const GlyfPartsBatch &l = w.plocal;
+		auto end_of = [&](uint32_t part) { return part < l.parts.size() ? l.parts[part].byte_off : (uint32_t)l.bytes.size(); };
+		s.n_cmd = l.slot_off[s.job1] - l.slot_off[s.job0];
+		s.n_dat = l.part_off[s.job1] - l.part_off[s.job0];
+		s.n_byte = end_of(l.part_off[s.job1]) - end_of(l.part_off[s.job0]);
 	}, true);
 	const double t1 = now_s();
 	timings_.tessellate_s += t1 - t0;
@@ -1403,15 +1408,14 @@ bool FontManager::fe_record_glyf(const std::vector<Todo> &tasks, FeGroup &G)
 	};
 	for (size_t i = 0; i < slices.size(); i++) {
 		OSlice &s = slices[i];
-		const GlyfPartsBatch &l = workers_[s.worker].plocal;
 		s.g_job = n_jobs;
 		G.slice_cmd[i] = n_slots;
 		G.slice_part[i] = n_parts;
 		G.slice_byte[i] = n_bytes;
 		n_jobs += s.job1 - s.job0;
-		n_slots += l.slot_off[s.job1] - l.slot_off[s.job0];
-		n_parts += l.part_off[s.job1] - l.part_off[s.job0];
-		n_bytes += byte_at(l, l.part_off[s.job1]) - byte_at(l, l.part_off[s.job0]);
+		n_slots += s.n_cmd;
+		n_parts += s.n_dat;
+		n_bytes += s.n_byte;
 	}
 	G.n_jobs = n_jobs;
 	MergedOutlines &m = G.m;
@@ -1507,6 +1511,8 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool all
 			if (const FontFileEntry *f = blk.glyphs[ci])
 				Renderer::record(f->face(), blk.start_index + ci, w.olocal);
 		s.job1 = (uint32_t)w.olocal.jobs.size();
+		s.n_cmd = w.olocal.cmd_off[s.job1] - w.olocal.cmd_off[s.job0];
+		s.n_dat = w.olocal.dat_off[s.job1] - w.olocal.dat_off[s.job0];
 	});
 	const double t1 = now_s();
 	timings_.tessellate_s += t1 - t0;
@@ -1517,13 +1523,12 @@ void FontManager::fe_record(const std::vector<Todo> &tasks, FeGroup &G, bool all
 	G.slice_dat.resize(slices.size());
 	for (size_t i = 0; i < slices.size(); i++) {
 		OSlice &s = slices[i];
-		const PackedOutlineBatch &l = workers_[s.worker].olocal;
 		s.g_job = n_jobs;
 		G.slice_cmd[i] = n_cmds;
 		G.slice_dat[i] = n_floats;
 		n_jobs += s.job1 - s.job0;
-		n_cmds += l.cmd_off[s.job1] - l.cmd_off[s.job0];
-		n_floats += l.dat_off[s.job1] - l.dat_off[s.job0];
+		n_cmds += s.n_cmd;
+		n_floats += s.n_dat;
 	}
 	G.n_jobs = n_jobs;
 	MergedOutlines &m = G.m;
@@ -1579,16 +1584,32 @@ void FontManager::fe_prepare_pieces(const std::vector<Todo> &tasks, FeGroup &G)
 	std::vector<uint8_t> &small = G.small;
 	small.resize(nb * small_stride);
 	G.busy.clear();
-	for (size_t i = 0; i < nb; i++) {
-		if (G.task_g0[i] != G.task_g0[i + 1]) {
-			G.busy.push_back((uint32_t)i);
-			continue;
-		}
+	auto empty_file = [&](size_t i) { // the file of a block without a glyph of this group: name + range
 		const Todo &td = tasks[G.g0 + i];
 		const std::string &range = td.block.range();
 		uint8_t *entries = small.data() + i * small_stride + kPbfHeadRoom + pbf_block_fields(td.name->size(), range.size());
 		uint8_t *file = write_pbf_block_header(entries, *td.name, range, 0);
 		piece[i] = Piece{file, (size_t)(entries - file)};
+	};
+	if (nb >= 1024) {
+		// many fonts in one group (21 fixture fonts: 2688 tasks per group, 2500 of them such files): 50 us on the calling
+		// thread, which a run over many fonts has no device latency to hide behind — runs of 128 tasks on the pool
+		constexpr size_t kRun = 128;
+		pool().run((nb + kRun - 1) / kRun, [&](size_t c, unsigned) {
+			for (size_t i = c * kRun; i < std::min(nb, (c + 1) * kRun); i++)
+				if (G.task_g0[i] == G.task_g0[i + 1])
+					empty_file(i);
+		}, true);
+		for (size_t i = 0; i < nb; i++)
+			if (G.task_g0[i] != G.task_g0[i + 1])
+				G.busy.push_back((uint32_t)i);
+	} else {
+		for (size_t i = 0; i < nb; i++) {
+			if (G.task_g0[i] != G.task_g0[i + 1])
+				G.busy.push_back((uint32_t)i);
+			else
+				empty_file(i);
+		}
 	}
 	timings_.encode_s += now_s() - t3;
 }
@@ -1741,7 +1762,9 @@ void FontManager::run_tasks_device_front_end(std::vector<Todo> &tasks, Writer &w
 	// groups — to overlap host and device — only when each keeps >= 5000 glyphs (measured in round 3, 32 threads on a
 	// 16-CPU quota: the 14 180 glyphs of the 21 fixture fonts 2.5 / 2.1 / 1.8 / 2.0 / 2.1 ms with groups of at least
 	// 2000 / 3500 / 5000 / 8000 / 20 000 glyphs; Noto Sans' 6445 glyphs 1.14 / 1.09 / 1.07 ms at 2000 / 5000 / 20 000).
-	// An explicit set_batch_blocks() bounds the group in blocks instead.
+	// An explicit set_batch_blocks() bounds the group in blocks instead.  (Round 4: a half-size FIRST group, to start the device
+	// earlier — 275 of the 21 fonts' 1110 us pass before the first submission — made three groups of two and the run slower,
+	// 1106 -> 1271 us: with the host phases of a group at 120-220 us whatever its size the run is bound by this thread.)
 	size_t total_glyphs = 0;
 	for (const Todo &t : tasks)
 		total_glyphs += t.block.len();

@@ -234,6 +234,9 @@ private:
 		unsigned worker = 0;
 		uint32_t job0 = 0, job1 = 0;
 		uint32_t g_job = 0; // first glyph index in the merged batch
+		// what the slice added to its worker's batch, noted by the worker while that batch is hot in its cache (the merge's
+		// serial pass then reads this array only): commands / command slots, coordinates / parts, bytes
+		uint32_t n_cmd = 0, n_dat = 0, n_byte = 0;
 	};
 	struct alignas(128) Worker { // own cache lines: the vector headers inside are written per glyph
 		TessScratch scratch;

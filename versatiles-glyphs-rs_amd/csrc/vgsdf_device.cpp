@@ -924,63 +924,72 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		ctx->err = "vgsdf_outlines: cmd_off[0] must be 0";
 		return VGSDF_E_ARG;
 	}
-	for (uint32_t g = 0; g < n; g++)
-		if (in->cmd_off[g + 1] < in->cmd_off[g]) {
-			ctx->err = "vgsdf_outlines: cmd_off not monotone";
-			return VGSDF_E_ARG;
-		}
 	const uint32_t n_cmds = n ? in->cmd_off[n] : 0;
 	if (n_cmds && !in->glyf && (in->packed ? !in->kinds : !in->cmds)) {
 		ctx->err = "vgsdf_outlines: NULL command array";
 		return VGSDF_E_ARG;
 	}
+	if (in->glyf && ((in->n_parts && (!in->parts || !in->bytes)) || (in->n_bytes & 3u))) {
+		ctx->err = "vgsdf_outlines_glyf: NULL parts / bytes, or n_bytes not a multiple of 4";
+		return VGSDF_E_ARG;
+	}
+	if (in->packed && n && (in->dat_off[0] != 0 || (in->dat_off[n] && !in->coords))) {
+		ctx->err = in->dat_off[0] != 0 ? "vgsdf_outlines: dat_off[0] must be 0" : "vgsdf_outlines: NULL coordinate array";
+		return VGSDF_E_ARG;
+	}
+	const uint32_t n_floats = in->packed && n ? in->dat_off[n] : 0u;
+	// The walks over the input — offsets monotone, parts tiling the command slots inside their glyphs and inside `bytes`, scales —
+	// are what every kernel's indexing rests on, so they come before the first kernel that reads the input; but not before the
+	// UPLOAD, which reads nothing of it: a single-block submission starts its copy first and validates under it (25 k entries
+	// of a 21-font group: ~45 us of this thread that the device used to wait for).
 	uint32_t glyf_max_cap = 0, glyf_max_len = 0;
 	bool parts_inside_glyphs = true; // every part's slots lie inside ONE glyph's range (what a sound caller sends)
-	if (in->glyf) {
-		// the parts tile the command slots in order, and their bytes lie inside `bytes` (what the bytes SAY is checked on
-		// the device, entry by entry)
-		if ((in->n_parts && (!in->parts || !in->bytes)) || (in->n_bytes & 3u)) {
-			ctx->err = "vgsdf_outlines_glyf: NULL parts / bytes, or n_bytes not a multiple of 4";
+	bool scales_plain = true;        // every scale positive and finite
+	auto validate = [&]() -> int {
+		uint32_t bad = 0;
+		for (uint32_t g = 0; g < n; g++) {
+			bad |= in->cmd_off[g + 1] < in->cmd_off[g];
+			scales_plain = scales_plain && in->scale[g] > 0.0 && in->scale[g] < HUGE_VAL;
+		}
+		if (bad) {
+			ctx->err = "vgsdf_outlines: cmd_off not monotone";
 			return VGSDF_E_ARG;
 		}
-		uint64_t slots = 0;
-		uint32_t gi = 0;
-		for (uint32_t i = 0; i < in->n_parts; i++) {
-			const vgsdf_glyf_part &pt = in->parts[i];
-			while (gi < n && in->cmd_off[gi + 1] <= pt.cmd_at)
-				gi++;
-			parts_inside_glyphs = parts_inside_glyphs && gi < n && pt.cmd_at >= in->cmd_off[gi] && (uint64_t)pt.cmd_at + pt.cmd_cap <= in->cmd_off[gi + 1];
-			glyf_max_cap = std::max(glyf_max_cap, pt.cmd_cap);
-			glyf_max_len = std::max(glyf_max_len, pt.byte_len);
-			if (pt.cmd_at != slots || (pt.byte_off & 3u) || pt.byte_off > in->n_bytes || pt.byte_len > in->n_bytes - pt.byte_off ||
-			    pt.n_contours == 0) {
-				ctx->err = "vgsdf_outlines_glyf: parts must tile the command slots in order, with 4-aligned byte ranges inside `bytes`";
+		if (in->glyf) {
+			// the parts tile the command slots in order, and their bytes lie inside `bytes` (what the bytes SAY is checked on
+			// the device, entry by entry)
+			uint64_t slots = 0;
+			uint32_t gi = 0;
+			for (uint32_t i = 0; i < in->n_parts; i++) {
+				const vgsdf_glyf_part &pt = in->parts[i];
+				while (gi < n && in->cmd_off[gi + 1] <= pt.cmd_at)
+					gi++;
+				parts_inside_glyphs = parts_inside_glyphs && gi < n && pt.cmd_at >= in->cmd_off[gi] && (uint64_t)pt.cmd_at + pt.cmd_cap <= in->cmd_off[gi + 1];
+				glyf_max_cap = std::max(glyf_max_cap, pt.cmd_cap);
+				glyf_max_len = std::max(glyf_max_len, pt.byte_len);
+				if (pt.cmd_at != slots || (pt.byte_off & 3u) || pt.byte_off > in->n_bytes || pt.byte_len > in->n_bytes - pt.byte_off ||
+				    pt.n_contours == 0) {
+					ctx->err = "vgsdf_outlines_glyf: parts must tile the command slots in order, with 4-aligned byte ranges inside `bytes`";
+					return VGSDF_E_ARG;
+				}
+				slots += pt.cmd_cap;
+			}
+			if (slots != n_cmds) {
+				ctx->err = "vgsdf_outlines_glyf: cmd_off[n_glyphs] differs from the parts' command slots";
 				return VGSDF_E_ARG;
 			}
-			slots += pt.cmd_cap;
 		}
-		if (slots != n_cmds) {
-			ctx->err = "vgsdf_outlines_glyf: cmd_off[n_glyphs] differs from the parts' command slots";
-			return VGSDF_E_ARG;
-		}
-	}
-	uint32_t n_floats = 0;
-	if (in->packed && n) {
-		if (in->dat_off[0] != 0) {
-			ctx->err = "vgsdf_outlines: dat_off[0] must be 0";
-			return VGSDF_E_ARG;
-		}
-		for (uint32_t g = 0; g < n; g++)
-			if (in->dat_off[g + 1] < in->dat_off[g]) {
+		if (in->packed) {
+			for (uint32_t g = 0; g < n; g++)
+				bad |= in->dat_off[g + 1] < in->dat_off[g];
+			if (bad) {
 				ctx->err = "vgsdf_outlines: dat_off not monotone";
 				return VGSDF_E_ARG;
 			}
-		n_floats = in->dat_off[n];
-		if (n_floats && !in->coords) {
-			ctx->err = "vgsdf_outlines: NULL coordinate array";
-			return VGSDF_E_ARG;
 		}
-	}
+		return VGSDF_OK;
+	};
+	bool validated = false;
 	// (the command kinds are checked on the device: the kernels treat an unknown kind as a no-op and the context
 	// pass raises the batch's error flag, so nothing unsafe runs and the host need not walk the commands)
 	(void)hipSetDevice(ctx->device);
@@ -1075,6 +1084,11 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 	const void *hb_mapped = nullptr;
 	if ((gblob || blob) && !(ck_env && ck_env[0] == '0') && ((uintptr_t)hb & 15u) == 0)
 		hb_mapped = pinned_device_ptr(const_cast<uint8_t *>(hb), gblob ? gl_total : blob_bytes);
+	if (!(hb_mapped != nullptr && (gblob || blob))) { // (not one block uploaded by a kernel: validate first, as ever)
+		if (int rc = validate(); rc != VGSDF_OK)
+			return rc;
+		validated = true;
+	}
 	// error word of this submission (FrontEnd::flag_slot)
 	if (!fe.flags_clean)
 		FE_TRY(hipMemsetAsync(fe.flag.p, 0, 32, st));
@@ -1165,14 +1179,16 @@ static int fe_submit(vgsdf_ctx *ctx, const FeInput *in, uint8_t *spec_out, size_
 		const size_t guess = fe.last_spans ? (size_t)fe.last_spans + fe.last_spans / 2 + 256 : fe.tile_cap;
 		p.launch_spans = (uint32_t)std::min<size_t>(std::min(guess, fe.tile_cap), 0x7FFFFFFFu);
 	}
+	if (!validated) { // the upload is under way: now the walks over the input, before the first kernel that reads it
+		if (int rc = validate(); rc != VGSDF_OK)
+			return rc;
+	}
 	// glyf form: the decoder writes the context bytes itself (the ring state follows from the contour rules) when no glyph
 	// of the batch has an odd scale (not positive and finite: bit 1 of the context byte, which only the context pass forms)
 	// and no part straddles two glyphs (the decoder's rule is per part; the ring pass trusts the context bytes to be those of
 	// the glyph's own command sequence — a byte that says "open" in front of a glyph's first command would index a ring
 	// that does not exist)
-	bool decode_makes_context = in->glyf && parts_inside_glyphs;
-	for (uint32_t g = 0; g < n && decode_makes_context; g++)
-		decode_makes_context = in->scale[g] > 0.0 && in->scale[g] < HUGE_VAL;
+	bool decode_makes_context = in->glyf && parts_inside_glyphs && scales_plain;
 	static const char *fuse_env = std::getenv("VGSDF_FUSE_CONTEXT"); // (measurement switch)
 	if (fuse_env && fuse_env[0] == '0')
 		decode_makes_context = false;
