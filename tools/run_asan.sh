@@ -12,5 +12,5 @@ mkdir -p oracle/build
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
   VGSDF_LIB=$PWD/versatiles-glyphs-rs_amd/build/asan/libvgsdf.so VG_ORACLE_LIB=$PWD/oracle/build/libvgoracle_asan.so \
   python -m pytest tests/test_host_facade.py tests/test_host_vs_oracle.py tests/test_capi_exports.py \
-    tests/test_cff_outlines.py tests/test_cff2_outlines.py tests/test_glyf_parts_host.py tests/test_font_collections.py tests/test_ingestion_and_sinks.py tests/test_pbf_layout_boundaries.py tests/test_large_font.py tests/test_glyph_sharding.py \
+    tests/test_cff_outlines.py tests/test_cff2_outlines.py tests/test_glyf_parts_host.py tests/test_font_collections.py tests/test_ingestion_and_sinks.py tests/test_pbf_layout_boundaries.py tests/test_large_font.py tests/test_glyph_sharding.py tests/test_composite_fanout.py tests/test_lane_plan.py \
     "tests/test_malformed_fonts.py::test_damaged_fonts_never_crash" -x -q -m "not gpu" -k "not links_from_c and not gloo"
