@@ -219,7 +219,10 @@ int vgsdf_outlines_submit_packed(vgsdf_ctx *ctx, const vgsdf_outlines_packed *in
  * (ttf-parser returns None for such a glyph and, in a composite, skips the components behind it) fails the whole batch with
  * VGSDF_E_GLYF in vgsdf_outlines_wait: the caller records that batch with its host reader and submits commands instead.
  * In ONE block from vgsdf_host_alloc() in the order scale | shift_x | cmd_off | (pad to a multiple of 8 bytes) | parts | bytes
- * [| pbf_pre | pbf_fix] the batch is uploaded with a single copy.  pbf_pre / pbf_fix as in vgsdf_outlines_packed. */
+ * [| pbf_pre | pbf_fix] the batch is uploaded with a single copy — by a kernel reading the block itself (it is device-mapped), so no
+ * copy-engine hand-over sits in front of the decoder — and its offsets are validated under that copy.  When every scale is positive
+ * and finite and no part's slots straddle two glyphs the decoder also notes the ring state in front of every callback (what
+ * ring_builder.rs:83-85,99-101 ask) and the separate context pass is skipped.  pbf_pre / pbf_fix as in vgsdf_outlines_packed. */
 typedef struct {
 	uint32_t byte_off, byte_len;
 	uint32_t cmd_at, cmd_cap;
