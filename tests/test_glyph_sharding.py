@@ -294,6 +294,23 @@ def test_hybrid_plan_with_split_blocks_gives_the_golden_files(vg, files):
             assert not bad, (fe, in_place, bad[:5])
             t = m.timings()
             assert m.reduced_counters() == (256, t["glyphs"], t["pixels"])
+    # the split blocks reach the native sinks as a header + the lanes' runs of entries (Writer::write_gather): same files
+    import tarfile
+    with tempfile.TemporaryDirectory() as d:
+        tw = vg.NativeWriter.new_tar(Path(d) / "o.tar", 7)
+        m.render_glyphs_to(tw, multi)
+        tw.finish()
+        tw.close()
+        with tarfile.open(Path(d) / "o.tar") as tf:
+            got = {mm.name: tf.extractfile(mm).read() for mm in tf.getmembers() if mm.isfile()}
+        assert got == w.files
+        (Path(d) / "tree").mkdir()
+        fw = vg.NativeWriter.new_file(Path(d) / "tree")
+        m.render_glyphs_to(fw, multi)
+        fw.finish()
+        fw.close()
+        tree = {str(q.relative_to(Path(d) / "tree")): q.read_bytes() for q in (Path(d) / "tree").rglob("*.pbf")}
+        assert tree == w.files
     multi.close()
 
 

@@ -58,6 +58,11 @@ struct CallbackWriter final : vg::Writer {
 		if (cb && cb(user, p.c_str(), d, n, 0) != 0)
 			throw std::runtime_error("writer callback failed for " + p);
 	}
+	void write_gather(const std::string &p, const Piece *pieces, size_t n) override
+	{
+		if (cb) // (the callback takes one buffer: joined by the default; the NULL sink has nothing to join for)
+			vg::Writer::write_gather(p, pieces, n);
+	}
 };
 } // namespace
 

@@ -763,7 +763,8 @@ std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_
 // the entries of a part are already in ascending id and stay together, so the block's file is its header followed by the
 // parts' entry regions as they are — three or four copies instead of a walk over every glyph message.  The first ids of the
 // parts must ascend (checked); anything unexpected goes to merge_pbf_partials.
-std::vector<uint8_t> concat_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts)
+bool plan_pbf_concat(const std::vector<std::pair<const uint8_t *, size_t>> &parts, std::vector<uint8_t> &head,
+                     std::vector<std::pair<const uint8_t *, size_t>> &pieces)
 {
 	auto varint = [](const uint8_t *&p, const uint8_t *end, uint64_t &v) {
 		v = 0;
@@ -775,56 +776,69 @@ std::vector<uint8_t> concat_pbf_partials(const std::vector<std::pair<const uint8
 		}
 		return false;
 	};
-	struct Region {
-		const uint8_t *p;
-		size_t n;
-	};
-	std::vector<Region> regions;
+	head.clear();
+	pieces.clear();
 	const uint8_t *fields = nullptr; // name + range fields of the first part
 	size_t fields_n = 0;
 	uint64_t last_first_id = 0;
+	bool any = false;
 	for (const auto &part : parts) {
 		const uint8_t *p = part.first, *end = p + part.second;
 		uint64_t len;
 		if (p == end || *p++ != 0x0A || !varint(p, end, len) || len != (uint64_t)(end - p))
-			return merge_pbf_partials(parts);
+			return false;
 		const uint8_t *f0 = p;
 		for (int k = 0; k < 2; k++) { // 0x0A name, 0x12 range (fontstack.rs:9-25: in tag order)
 			if (p == end || *p++ != (k ? 0x12 : 0x0A) || !varint(p, end, len) || len > (uint64_t)(end - p))
-				return merge_pbf_partials(parts);
+				return false;
 			p += len;
 		}
 		if (!fields) {
 			fields = f0;
 			fields_n = (size_t)(p - f0);
 		} else if ((size_t)(p - f0) != fields_n || std::memcmp(f0, fields, fields_n) != 0) {
-			return merge_pbf_partials(parts); // (throws: parts of different blocks)
+			return false; // (parts of different blocks: merge_pbf_partials says so)
 		}
 		if (p == end)
 			continue; // a part without glyphs
 		const uint8_t *q = p;
 		uint64_t glen, id;
-		if (*q++ != 0x1A || !varint(q, end, glen) || q == end || *q++ != 0x08 || !varint(q, end, id) || (!regions.empty() && id <= last_first_id))
-			return merge_pbf_partials(parts);
+		if (*q++ != 0x1A || !varint(q, end, glen) || q == end || *q++ != 0x08 || !varint(q, end, id) || (any && id <= last_first_id))
+			return false;
 		last_first_id = id;
-		regions.push_back(Region{p, (size_t)(end - p)});
+		any = true;
+		pieces.emplace_back(p, (size_t)(end - p));
 	}
+	if (!fields)
+		return false;
 	size_t stack = fields_n;
-	for (const Region &r : regions)
-		stack += r.n;
-	std::vector<uint8_t> out;
-	out.reserve(stack + 8);
-	out.push_back(0x0A);
+	for (const auto &r : pieces)
+		stack += r.second;
+	head.push_back(0x0A);
 	for (uint64_t v = stack;; v >>= 7) {
 		if (v < 0x80) {
-			out.push_back((uint8_t)v);
+			head.push_back((uint8_t)v);
 			break;
 		}
-		out.push_back((uint8_t)(v | 0x80));
+		head.push_back((uint8_t)(v | 0x80));
 	}
-	out.insert(out.end(), fields, fields + fields_n);
-	for (const Region &r : regions)
-		out.insert(out.end(), r.p, r.p + r.n);
+	head.insert(head.end(), fields, fields + fields_n);
+	pieces.insert(pieces.begin(), std::make_pair((const uint8_t *)head.data(), head.size()));
+	return true;
+}
+
+std::vector<uint8_t> concat_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts)
+{
+	std::vector<uint8_t> head, out;
+	std::vector<std::pair<const uint8_t *, size_t>> pieces;
+	if (!plan_pbf_concat(parts, head, pieces))
+		return merge_pbf_partials(parts);
+	size_t total = 0;
+	for (const auto &pc : pieces)
+		total += pc.second;
+	out.reserve(total);
+	for (const auto &pc : pieces)
+		out.insert(out.end(), pc.first, pc.first + pc.second);
 	return out;
 }
 
@@ -862,6 +876,13 @@ struct CaptureWriter final : Writer {
 	size_t size(size_t i) const { return files[i].len; }
 	void write_directory(const std::string &) override {}
 	void write_file(const std::string &path, const std::vector<uint8_t> &d) override { write_bytes(path, d.data(), d.size()); }
+	void write_gather(const std::string &, const Piece *pieces, size_t n) override
+	{
+		const size_t at = store.size();
+		for (size_t i = 0; i < n; i++)
+			store.insert(store.end(), pieces[i].first, pieces[i].first + pieces[i].second);
+		files.push_back(File{at, store.size() - at});
+	}
 	void write_bytes(const std::string &, const uint8_t *d, size_t len) override
 	{
 		files.push_back(File{store.size(), len});
@@ -1156,29 +1177,35 @@ void FontManager::render_tasks_multi(Writer &writer, const Renderer &renderer, i
 		if (parts[r].files.size() != lane_tasks[r].size())
 			throw std::runtime_error("render_glyphs: a device lane produced " + std::to_string(parts[r].files.size()) + " files instead of " +
 			                         std::to_string(lane_tasks[r].size()));
-	// the split blocks: their parts hold disjoint glyph subsets of one block and are merged into the block's file
+	// the split blocks: their parts hold consecutive runs of one block's glyphs and are handed to the sink as they lie — the
+	// block's header and the lanes' entry regions (Writer::write_gather) — instead of being joined first
 	const std::vector<LanePlan::Split> &splits = lane_plan_.splits;
-	std::vector<std::vector<uint8_t>> merged(splits.size());
-	if (!splits.empty())
-		pool().run(splits.size(), [&](size_t k, unsigned) {
-			std::vector<std::pair<const uint8_t *, size_t>> ps;
-			for (uint32_t pi = 0; pi < splits[k].n_parts; pi++) {
-				const CaptureWriter &lane = parts[lane_plan_.part_owner[splits[k].first_part + pi]];
-				const uint32_t at = lane_plan_.part_slot[splits[k].first_part + pi];
-				ps.emplace_back(lane.data(at), lane.size(at));
-			}
-			merged[k] = concat_pbf_partials(ps);
-		});
 	const double t_merged = now_s();
 	timings_ = RenderTimings{};
 	for (const std::string *name : names)
 		writer.write_directory(*name + "/");
 	std::string path;
+	std::vector<std::pair<const uint8_t *, size_t>> ps, pieces;
+	std::vector<uint8_t> head;
 	for (size_t i = 0; i < all.size(); i++) {
 		all[i].block.path_into(*all[i].name, path);
 		if (owner[i] == LanePlan::kSplit) {
-			writer.write_bytes(path, merged[slot[i]].data(), merged[slot[i]].size());
-			timings_.pbf_bytes += merged[slot[i]].size();
+			const LanePlan::Split &sp = splits[slot[i]];
+			ps.clear();
+			for (uint32_t pi = 0; pi < sp.n_parts; pi++) {
+				const CaptureWriter &lane = parts[lane_plan_.part_owner[sp.first_part + pi]];
+				const uint32_t at = lane_plan_.part_slot[sp.first_part + pi];
+				ps.emplace_back(lane.data(at), lane.size(at));
+			}
+			if (plan_pbf_concat(ps, head, pieces)) {
+				writer.write_gather(path, pieces.data(), pieces.size());
+				for (const auto &pc : pieces)
+					timings_.pbf_bytes += pc.second;
+			} else {
+				const std::vector<uint8_t> joined = merge_pbf_partials(ps);
+				writer.write_bytes(path, joined.data(), joined.size());
+				timings_.pbf_bytes += joined.size();
+			}
 			continue;
 		}
 		const CaptureWriter &lane = parts[owner[i]];

@@ -39,6 +39,16 @@ struct Writer {
 	// the same for bytes that live in someone else's buffer (a block assembled in place in the device's output arena):
 	// sinks that can take a pointer override it and save the copy
 	virtual void write_bytes(const std::string &path, const uint8_t *data, size_t len) { write_file(path, std::vector<uint8_t>(data, data + len)); }
+	// ... and for a file whose bytes lie in several places (a block whose glyphs were rendered by several device lanes: its
+	// header and the lanes' runs of entries): sinks that stream override it; the default joins the pieces first
+	using Piece = std::pair<const uint8_t *, size_t>;
+	virtual void write_gather(const std::string &path, const Piece *pieces, size_t n)
+	{
+		std::vector<uint8_t> all;
+		for (size_t i = 0; i < n; i++)
+			all.insert(all.end(), pieces[i].first, pieces[i].first + pieces[i].second);
+		write_bytes(path, all.data(), all.size());
+	}
 	virtual void finish() {} // writer/mod.rs:71-77
 };
 
@@ -378,5 +388,9 @@ std::string name_to_id(const std::string &name); // manager.rs:141-147
 std::vector<uint8_t> merge_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts);
 // the same for parts that hold consecutive runs of the block's code points, in order: header + the parts' entries as they are
 std::vector<uint8_t> concat_pbf_partials(const std::vector<std::pair<const uint8_t *, size_t>> &parts);
+// the same without the copy: `head` receives the file's own bytes (length prefix, name and range), `pieces` head + the parts'
+// entry regions where they lie — for Writer::write_gather.  false: the parts are not in that form (use merge_pbf_partials)
+bool plan_pbf_concat(const std::vector<std::pair<const uint8_t *, size_t>> &parts, std::vector<uint8_t> &head,
+                     std::vector<std::pair<const uint8_t *, size_t>> &pieces);
 
 } // namespace vg

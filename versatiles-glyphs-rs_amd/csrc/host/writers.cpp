@@ -98,6 +98,19 @@ void TarWriter::write_file(const std::string &path, const std::vector<uint8_t> &
 	write_file(path, data.data(), data.size());
 }
 
+void TarWriter::write_gather(const std::string &path, const Piece *pieces, size_t n)
+{
+	static const uint8_t zeros[512] = {0};
+	size_t len = 0;
+	for (size_t i = 0; i < n; i++)
+		len += pieces[i].second;
+	header(path, len, 0644, '0');
+	for (size_t i = 0; i < n; i++)
+		put(pieces[i].first, pieces[i].second);
+	if (len % 512)
+		put(zeros, 512 - len % 512);
+}
+
 void TarWriter::write_directory(const std::string &path)
 {
 	if (path.empty() || path.back() != '/') // tar.rs:124
@@ -164,6 +177,19 @@ void FileWriter::write_file(const std::string &path, const uint8_t *data, size_t
 void FileWriter::write_file(const std::string &path, const std::vector<uint8_t> &data)
 {
 	write_file(path, data.data(), data.size());
+}
+
+void FileWriter::write_gather(const std::string &path, const Piece *pieces, size_t n)
+{
+	const std::string full = join(folder_, path);
+	std::FILE *f = std::fopen(full.c_str(), "wb");
+	if (!f)
+		throw std::runtime_error("writing \"" + full + "\": " + std::strerror(errno));
+	bool ok = true;
+	for (size_t i = 0; i < n && ok; i++)
+		ok = pieces[i].second == 0 || std::fwrite(pieces[i].first, 1, pieces[i].second, f) == pieces[i].second;
+	if (std::fclose(f) != 0 || !ok)
+		throw std::runtime_error("writing \"" + full + "\": " + std::strerror(errno));
 }
 
 } // namespace vg

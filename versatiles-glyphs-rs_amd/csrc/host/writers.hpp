@@ -28,6 +28,7 @@ public:
 	void write_file(const std::string &path, const std::vector<uint8_t> &data) override;
 	void write_file(const std::string &path, const uint8_t *data, size_t len);
 	void write_bytes(const std::string &path, const uint8_t *data, size_t len) override { write_file(path, data, len); }
+	void write_gather(const std::string &path, const Piece *pieces, size_t n) override; // one header, the pieces streamed
 	void finish() override;
 
 private:
@@ -49,6 +50,7 @@ public:
 	void write_file(const std::string &path, const std::vector<uint8_t> &data) override;
 	void write_file(const std::string &path, const uint8_t *data, size_t len);
 	void write_bytes(const std::string &path, const uint8_t *data, size_t len) override { write_file(path, data, len); }
+	void write_gather(const std::string &path, const Piece *pieces, size_t n) override;
 
 private:
 	std::string folder_;
