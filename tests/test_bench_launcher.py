@@ -78,3 +78,27 @@ def test_fewer_devices_than_ranks_is_a_labelled_rehearsal_and_a_failed_attempt_i
     assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert out["launcher"]["attempt"] == 2 and attempts[1]["VG_DIST_BACKEND"] == "gloo" and "VG_DIST_BACKEND" not in attempts[0]
+
+
+def test_last_resort_sums_independent_one_device_processes(bench, monkeypatch, capsys):
+    """both launcher attempts die without a line: N one-device processes, no rendezvous, labelled as such"""
+    def dead(cmd, **kw):
+        if "-c" in cmd:
+            return subprocess.CompletedProcess(cmd, 0, stdout="2\n", stderr="")
+        return subprocess.CompletedProcess(cmd, 1, stdout="", stderr="")
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, **kw):
+            started.append((cmd, env))
+            self.rank = len(started) - 1
+
+        def communicate(self, timeout=None):
+            return json.dumps({"value": 10.0 + self.rank, "mpixel_sdf_per_s": 1.0, "ms_per_step": 0.1 + self.rank, "n_gpus": 1}) + "\n", None
+    monkeypatch.setattr(subprocess, "run", dead)
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    assert bench.launch_ranks(2, ["--gpus", "2", "--steps", "5"]) == 0
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["value"] == 21.0 and out["n_gpus"] == 2 and out["ms_per_step"] == 1.1 and "LAST RESORT" in out["launcher"]["form"]
+    assert [e["HIP_VISIBLE_DEVICES"] for _, e in started] == ["0", "1"]
+    assert all(c[c.index("--gpus") + 1] == "1" and "--no-e2e" in c for c, _ in started)
