@@ -28,4 +28,16 @@ print(f"{'start us':>9} {'dur us':>8} {'gap us':>7}  activity")
 for s, e, n in run:
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:7.1f}  {n}")
     prev_end = max(prev_end, e)
-print(f"span {(prev_end - t0) / 1e3:.1f} us, busy {sum(e - s for s, e, _ in run) / 1e3:.1f} us")
+# device busy = union of the intervals (two groups in flight overlap on two streams)
+busy, cur_s, cur_e = 0, None, None
+for s_, e_, _ in run:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+busy += (cur_e - cur_s) if cur_e is not None else 0
+span = prev_end - t0
+print(f"span {span / 1e3:.1f} us, sum of durations {sum(e - s for s, e, _ in run) / 1e3:.1f} us, device busy (union) {busy / 1e3:.1f} us = "
+      f"{100.0 * busy / span:.0f} % of the span (the span starts at the first device activity: the host's recording in front of it is not in it)")
