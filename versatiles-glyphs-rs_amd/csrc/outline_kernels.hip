@@ -1866,6 +1866,12 @@ extern "C" int vgsdf_outline_plan(const OutlineRect *rects, uint32_t n_glyphs, i
 	if (pbf_fix != nullptr && n_glyphs <= 4u * kPlanThreads)
 		hipLaunchKernelGGL((outline_plan<4, true>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
 		                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at, next_flag);
+	else if (pbf_fix != nullptr && n_glyphs <= 8u * kPlanThreads)
+		// groups of 4097 .. 8192 glyphs (the dispatcher's groups of several fonts: ~7000): eight placements per thread spill
+		// to scratch, and still beat the unkept path below, which reads and classifies every rect twice (21 fonts in two
+		// groups: 48 / 90 us per plan)
+		hipLaunchKernelGGL((outline_plan<8, true>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
+		                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at, next_flag);
 	else
 	hipLaunchKernelGGL((outline_plan<8, false>), dim3(1), dim3(kPlanThreads), 0, stream, rects, n_glyphs, span_list, delta_cap, span_max,
 	                   span_budget, tile_cap, descs, tiles, hdr, error_flag, seg_cap, out_cap, launch_spans, pbf_pre, pbf_fix, pbf_at, next_flag);
