@@ -73,7 +73,8 @@ def test_font_manager_takes_the_device_decoder_and_writes_the_same_files(vg):
             mgr.render_glyphs(w, r)
             files[on] = w.files
             t = mgr.timings()
-            assert t["glyphs"] > 1000 and t["glyf_groups"] == (1 if on else 0) and t["glyf_fallbacks"] == 0
+            # (one group per >= 3000 glyphs of a font: Fira's 1686 glyphs are one, the 6480 of the 20 Noto files two)
+            assert t["glyphs"] > 1000 and t["glyf_groups"] == ((2 if key == "noto_all" else 1) if on else 0) and t["glyf_fallbacks"] == 0
         assert files[True] == files[False]
         want = golden[key]
         got = {k.split("/", 1)[1].split("-")[0]: hashlib.sha256(v).hexdigest() for k, v in files[True].items()}
