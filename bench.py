@@ -41,6 +41,12 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run one after the
+# other.  The end-to-end path keeps two groups in flight on two device contexts (2 streams each) and this benchmark holds more
+# contexts beside them (resident batches, torch): on 4 queues the two groups landed on ONE queue and ran in sequence (Noto Sans all
+# files 8.9 instead of 11.2 M glyphs/s end to end, the 21 fonts 10.9 instead of 13.2 M).  Must be set before the HIP runtime starts;
+# the library does the same at load time when nothing has started it yet (vgsdf_device.cpp).  Reported in the line (`config.env`).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WORKLOADS = {
     # name: (font display name, [files relative to testdata/])
@@ -549,6 +555,7 @@ def main():
             "collectives": ("none" if world == 1 else f"{backend}: barrier, max(time), sum of 3 counters"),
             "collectives_fallback": coll_fallback,  # not None: RCCL was asked for and did not come up (said loudly here)
             "timed_region_ms": elapsed * 1e3,
+            "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         },
         "mpixel_sdf_per_s": counters[2] * steps / elapsed * 1e-6,
         "roofline": {
