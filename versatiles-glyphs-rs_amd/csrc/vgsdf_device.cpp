@@ -71,7 +71,13 @@ inline void *pinned_device_ptr(void *p, size_t bytes)
 // front-end with the other's raster is gone (measured in bench.py's process: Noto Sans all files 8.9 instead of 11.2 M glyphs/s).
 // The variable is read when the HIP runtime starts, i.e. at the process's first HIP call: when this library is loaded before
 // that and the variable is unset, 8 queues are asked for.  A host that starts HIP first sets it itself.
-__attribute__((constructor)) static void vgsdf_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// (VGSDF_KEEP_HW_QUEUES=1 in the environment: the library leaves the variable alone.)
+__attribute__((constructor)) static void vgsdf_default_hw_queues()
+{
+	const char *keep = std::getenv("VGSDF_KEEP_HW_QUEUES");
+	if (!(keep && keep[0] == '1'))
+		(void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
 
 struct vgsdf_ctx {
 	int device = 0;
